@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the latent-feature-grid sample/decode hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete full-volume reconstruction pass of the hot path (BASELINE.json north_star /
+metric: "Msamples/s (grid-interp+embed+MLP fwd) on 256^3 volume"): inverse-wavelet decode of the latent
+grid (once per pass, as an inference call does), parameter packing, then the fused trilinear-sample +
+Fourier-embed + 4-layer SnakeAlt MLP forward over every voxel of a 256^3 lattice (512 tiles of 32^3;
+positions generated per tile on device), fp32.  Model = BASELINE configs[2]/[3] shape (64^3 x 32-channel
+grid, 4-level db2 wavelet code, MLP 4 x 128), synthetic random-init parameters (no datasets offline).
+With N > 1 ranks the tile lattice is cut into contiguous x-slabs (strong scaling: the volume is fixed)
+and the output volume is assembled with ONE RCCL all-gather over xGMI.
+
+Rank 0 prints one JSON line.  `roofline` is for the dominant kernel (lfgc_fwd_kernel): algorithmic fp32
+MLP FLOPs per launch / its average launch duration (HIP events on the launch stream) against the dense
+fp32 MFMA peak; the HBM-side figure on the algorithmic gather bytes is reported next to it.
+`cpu_baseline` times the oracle's op-for-op PyTorch restatement of the reference on the host cores for a
+bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
+HBM_PEAK_GBS = 8000.0              # same guide, HBM3E spec
+
+WORKLOADS = {
+    # name: (volume edge, grid channels C, grid edge G, hidden H, layers L)
+    'headline': dict(vol=256, C=32, G=64, H=128, L=4,
+                     desc='256^3 full-volume reconstruction, 64^3x32ch grid (4-level db2), MLP 4x128, fp32'),
+    'cfg2': dict(vol=150, C=16, G=32, H=64, L=4,
+                 desc='150^3 full-volume reconstruction, 32^3x16ch grid (3-level db2), MLP 4x64, fp32'),
+}
+
+
+def build_model(w, seed, device):
+    """Random-init model of the named architecture: dense grid U(0,1) (model/model_utils.py:27-28) DWT-encoded
+    by the constructor, Linear layers U(+-1/sqrt(fan_in)); numpy PCG64 so every rank builds identical weights."""
+    from latent_feature_grid_compression_amd.model.Feature_Grid_Model import Feature_Grid_Model
+    from latent_feature_grid_compression_amd.model.Feature_Embedding import FourierEmbedding
+    from latent_feature_grid_compression_amd.wavelet_transform.Torch_Wavelet_Transform import WaveletFilter3d
+    rng = np.random.Generator(np.random.PCG64(seed))
+    grid = torch.from_numpy(rng.random((w['C'], w['G'], w['G'], w['G']), dtype=np.float32)).to(device)
+    model = Feature_Grid_Model(FourierEmbedding(2, 3), grid, None, WaveletFilter3d('db2').to(device),
+                               hidden_channel=w['H'], num_layer=w['L'])
+    with torch.no_grad():
+        for lin in list(model.net_layers) + [model.final_layer]:
+            bound = 1.0 / math.sqrt(lin.in_features)
+            lin.weight.copy_(torch.from_numpy(rng.uniform(-bound, bound, tuple(lin.weight.shape)).astype(np.float32)))
+            lin.bias.copy_(torch.from_numpy(rng.uniform(-bound, bound, tuple(lin.bias.shape)).astype(np.float32)))
+    return model.to(device).eval()
+
+
+def cpu_baseline(model, w, budget_s=20.0):
+    """Oracle (op-for-op torch restatement of the reference) on the host cores, bounded sample of the workload."""
+    from oracle import ref_torch as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    coeffs = [p.detach().cpu() for p in model.feature_grid]
+    layers = list(model.net_layers) + [model.final_layer]
+    weights = [l.weight.detach().cpu() for l in layers]
+    biases = [l.bias.detach().cpu() for l in layers]
+    frev = model.filter.filter_rev.detach().cpu()
+    ds = R.VolumeIndexing((w['vol'],) * 3)
+    tiles = list(R.tile_iter(ds.vol_res_touple, 32))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        dense = R.decode_volume(coeffs, model.shape_array, frev)
+        t_decode = time.perf_counter() - t0
+        # warm-up tile
+        R.forward_from_grid(dense, weights, biases, R.tile_positions(ds, tiles[0]).reshape(-1, 3), 2)
+        n_samples, n_tiles, t_fwd = 0, 0, 0.0
+        for b in tiles:
+            pos = R.tile_positions(ds, b).reshape(-1, 3)
+            t0 = time.perf_counter()
+            y = R.forward_from_grid(dense, weights, biases, pos, 2).clamp(-1, 1)
+            t_fwd += time.perf_counter() - t0
+            n_samples += pos.shape[0]
+            n_tiles += 1
+            if t_fwd > budget_s or n_tiles >= 64:
+                break
+    return {
+        'value': n_samples / t_fwd / 1e6, 'unit': 'Msamples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+        'sample': '%d tiles of 32^3 (%d samples) of the same lattice, grid decoded once (%.3f s, not included); '
+                  'with the reference\'s per-tile decode: %.4f Msamples/s'
+                  % (n_tiles, n_samples, t_decode, n_samples / (t_fwd + n_tiles * t_decode) / 1e6),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='headline', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X (no CPU fallback for the HIP path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    from latent_feature_grid_compression_amd.visualization import OutputToVTK as V
+    from latent_feature_grid_compression_amd import ops
+
+    w = WORKLOADS[args.workload]
+    model = build_model(w, seed=2003, device=device)
+    ds = IndexDataset((w['vol'],) * 3, 16, build_index_table=False)
+    res = ds.vol_res_touple
+    parts = V.slab_partition(res[0], world, 32)
+    my_b, my_e = parts[rank]
+    my_samples = (my_e - my_b) * res[1] * res[2]
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    step_state = {'i': -1}
+
+    def slab_fn(b, e, out_view):
+        # the fused forward of this rank's slab; events bracket exactly the dominant kernel's launch
+        with torch.no_grad():
+            grid_cl = model._decoded_channel_last()
+            packed = model._packed()
+            i = step_state['i']
+            if i >= 0:
+                ev[i][0].record()
+            ops.forward_raw(model._descriptor(), grid_cl, packed, pos=None, lattice=(res, b, e, 32), clamp=True,
+                            out=out_view.view(-1))
+            if i >= 0:
+                ev[i][1].record()
+
+    def one_step():
+        model._grid_cache = None          # every pass decodes the wavelet-coded grid and re-packs: no cached outputs
+        model._pack_cache = None
+        return V.reconstruct_volume_sharded(ds, model, 32, slab_fn=slab_fn, device=device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        vol = one_step()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_state['i'] = i
+        vol = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    step_state['i'] = -1
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+    assert tuple(vol.shape) == tuple(res) and bool(torch.isfinite(vol).all())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if my_samples > 0 else float('nan')
+    total_samples = res[0] * res[1] * res[2]
+    value = total_samples * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        K0 = 3 + 12 + w['C']
+        flop_per_sample = 2 * (K0 * w['H'] + (w['L'] - 1) * w['H'] ** 2 + w['H'])
+        bytes_per_sample = 12 + 4 + 8 * w['C'] * 4
+        achieved_tflops = flop_per_sample * my_samples / (kern_ms * 1e-3) / 1e12
+        hbm_alg_gbs = bytes_per_sample * my_samples / (kern_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'Msamples/s (grid-interp+embed+MLP fwd) on 256^3 volume' if args.workload == 'headline'
+                      else 'Msamples/s (grid-interp+embed+MLP fwd)',
+            'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': w['desc'], 'samples_per_step': total_samples, 'tiles': 'x-slabs of 32^3 tiles',
+                       'parallelism': 'tile-slab x%d + one all-gather' % world if world > 1 else 'single GPU',
+                       'step_includes': 'wavelet decode + param pack + fused forward' + (' + RCCL all-gather' if world > 1 else '')},
+            'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved_tflops / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': 'lfgc_fwd_kernel', 'kernel_ms': kern_ms, 'samples_per_launch': my_samples,
+                         'flop_per_sample': flop_per_sample,
+                         'hbm_algorithmic': {'bytes_per_sample': bytes_per_sample, 'achieved_GBs': hbm_alg_gbs,
+                                             'peak_GBs': HBM_PEAK_GBS, 'frac': hbm_alg_gbs / HBM_PEAK_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(model, w)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

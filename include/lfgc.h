@@ -1,0 +1,175 @@
+/* lfgc.h -- C-ABI of liblfgc.so: the MI355X (gfx950) implementation of the latent-feature-grid
+ * sample/decode hot path of Bussler/Latent_Feature_Grid_Compression.
+ *
+ * The reference has no FFI: its "interface" for this path is the Python nn.Module
+ * model/Feature_Grid_Model.py (forward :50-80, decode_volume :102-108, encode_volume :83-99), the
+ * wavelet filter wavelet_transform/Torch_Wavelet_Transform.py (encode :75-89, decode :91-104) and
+ * the ground-truth sampler data/Interpolation.py:8-44.  Each entry point below names the reference
+ * lines it replaces.  INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer marked "device" is a HIP device pointer owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); "host" pointers are ordinary host memory read before the call returns;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream); the
+ *     call returns without synchronising; no entry point allocates device memory or synchronises;
+ *   - return value: 0 = LFGC_OK, negative = LFGC_E_* argument/shape error (nothing was launched),
+ *     positive = the hipError_t of a failed launch.  Never aborts, never throws;
+ *   - all floating-point data is IEEE fp32, tensors are dense/contiguous in the stated layout.
+ */
+#ifndef LFGC_H
+#define LFGC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFGC_VERSION 100          /* 0.1.0 */
+#define LFGC_MAX_LAYERS 8         /* hidden layers (reference default 4, model/Feature_Grid_Model.py:18) */
+
+enum {
+    LFGC_OK = 0,
+    LFGC_E_NULL = -1,             /* required pointer is NULL */
+    LFGC_E_SHAPE = -2,            /* negative / zero / inconsistent extent */
+    LFGC_E_UNSUPPORTED = -3,      /* shape outside the compiled kernel set (see lfgc_mlp_supported) */
+    LFGC_E_ALIGN = -4,            /* pointer not 16-byte aligned where required */
+    LFGC_E_WORKSPACE = -5         /* workspace / packed buffer too small */
+};
+
+typedef void* lfgc_stream_t;      /* hipStream_t */
+
+int lfgc_version(void);
+const char* lfgc_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Wavelet transform of the feature grid
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One inverse-DWT level.  Replaces _WaveletFilterNd.decode + _unpad_for_reverse
+ * (wavelet_transform/Torch_Wavelet_Transform.py:91-104, :69-73) as called per level from
+ * Feature_Grid_Model.decode_volume (model/Feature_Grid_Model.py:104-107): torch.cat of the LLL band
+ * with the 7 detail bands, grouped conv_transpose3d (stride 2, 4^3 taps), crop to `t`.
+ *   lll        device (C, d0,d1,d2)           low band (coarse parameter or previous level's output)
+ *   hf         device (C, 7, d0,d1,d2)        detail bands, sub-band s = 4a+2b+c stored at hf[:, s-1]
+ *   filter_rev device (8, 4,4,4)              the module's `filter.filter_rev` buffer (fp32)
+ *   out        device (C, t0,t1,t2) if !channel_last_out, else (t0,t1,t2, C_pad) with C_pad =
+ *              out_channel_stride >= C (channels [C, C_pad) are written as 0)
+ * Requires 2*d_a + 2 >= t_a >= 1. */
+int lfgc_idwt_level_f32(const float* lll, const float* hf, const float* filter_rev, float* out,
+                        int C, int d0, int d1, int d2, int t0, int t1, int t2,
+                        int channel_last_out, int out_channel_stride, lfgc_stream_t stream);
+
+/* Adjoint of lfgc_idwt_level_f32 (what autograd derives for the ops above; triggered at
+ * training/training.py:137): d_lll (C,d0,d1,d2) and d_hf (C,7,d0,d1,d2) are OVERWRITTEN with the
+ * gradients given d_out in the same layout as `out` above. */
+int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_rev, float* d_lll, float* d_hf,
+                            int C, int d0, int d1, int d2, int t0, int t1, int t2,
+                            int channel_last_out, int out_channel_stride, lfgc_stream_t stream);
+
+/* One forward-DWT level (init only).  Replaces _WaveletFilterNd.encode incl. _pad_for_forward
+ * (wavelet_transform/Torch_Wavelet_Transform.py:59-67, :75-89): zero-pad (2, 2 + odd) per axis,
+ * grouped conv3d stride 2.  in (C, n0,n1,n2) -> out (C, 8, d0,d1,d2), d_a = (n_a + pad_hi_a) / 2 + 1 - ...
+ * exactly: d_a = (n_a + 2 + 2 + odd_a' - 4) / 2 + 1 where odd_a' is the reference's pad-slot quirk
+ * (the odd bit of axis a lands on axis 2-a).  filter_fwd device (8,4,4,4). */
+int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, float* out,
+                       int C, int n0, int n1, int n2, lfgc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused sample + Fourier-embed + MLP decoder
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Shape of the decoder network (model/Feature_Grid_Model.py:37-48). */
+typedef struct lfgc_mlp_desc {
+    int32_t grid_channels;   /* C  = feature_grid.shape[0]                                   */
+    int32_t hidden;          /* H  = hidden_channel                                           */
+    int32_t num_layers;      /* L  = num_layer  (L hidden Linear+SnakeAlt, then final Linear) */
+    int32_t n_freqs;         /* FourierEmbedding n_freqs (model/Feature_Embedding.py:20-34)   */
+    int32_t d_in;            /* must be 3 */
+    int32_t d_out;           /* must be 1 */
+} lfgc_mlp_desc;
+
+/* 1 if the compiled kernel set covers this shape (C <= 64, H <= 128, L <= 8, n_freqs <= 4, d_in 3, d_out 1). */
+int lfgc_mlp_supported(const lfgc_mlp_desc* desc);
+
+/* Channel stride (floats) the sampler expects for the channel-last dense grid: C rounded up to 8. */
+int lfgc_grid_channel_stride(int C);
+
+/* Bytes of the packed-parameter blob and of the per-call stash (N samples) for this network. */
+int64_t lfgc_packed_bytes(const lfgc_mlp_desc* desc);
+int64_t lfgc_stash_bytes(const lfgc_mlp_desc* desc, int64_t n_samples);
+
+/* Re-lay the nn.Linear parameters (weights[l] (out,in) row-major, biases[l] (out), l = 0..L with l = L
+ * the final layer; host arrays of L+1 device pointers; named_parameters() order of
+ * model/Feature_Grid_Model.py:43-48) into the blob the kernels read.  Run again whenever a parameter
+ * changes.  `packed` device, >= lfgc_packed_bytes(), 16-byte aligned. */
+int lfgc_pack_mlp_f32(const lfgc_mlp_desc* desc, const float* const* weights, const float* const* biases,
+                      float* packed, lfgc_stream_t stream);
+
+/* Where the sample positions come from. */
+typedef struct lfgc_positions {
+    const float* pos;        /* device (N,3) normalised positions, or NULL to generate the lattice below */
+    int64_t n;               /* number of samples when pos != NULL */
+    /* pos == NULL: full-volume lattice of visualization/OutputToVTK.py:11-37 (field_from_net), x-slab
+     * [x_begin, x_end) of a (res0,res1,res2) volume cut into tiles of `tile` voxels; sample order =
+     * row-major (x,y,z) of the slab, i.e. out[(x-x_begin)*res1*res2 + y*res2 + z].  Positions are formed
+     * per tile exactly as the reference does (linspace(start,end,n) -> *2-1 -> *scales, fp32). */
+    int32_t res[3];
+    int32_t x_begin, x_end;
+    int32_t tile;            /* reference: 32 */
+} lfgc_positions;
+
+/* forward().  Replaces model/Feature_Grid_Model.py:62-78 (everything after decode_volume):
+ * F.grid_sample(bilinear, align_corners=False, zeros) of the dense grid, Embedder.embed
+ * (model/Feature_Embedding.py:14-16), torch.cat, L x (Linear + SnakeAlt), final Linear, optional
+ * clamp(-1,1) (eval branch :78).
+ *   grid_cl   device (D,H,W,Cs) channel-last dense grid, Cs = lfgc_grid_channel_stride(C)
+ *   packed    device blob from lfgc_pack_mlp_f32
+ *   out       device (N) fp32  (= the (N,1) result)
+ *   stash     device, lfgc_stash_bytes(N) bytes, or NULL.  When given, the layer-0 input and every
+ *             pre-activation are saved for lfgc_backward_f32 (private layout). */
+int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
+                     const float* grid_cl, int D, int H, int W,
+                     const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream);
+
+/* Backward of lfgc_forward_f32 (what autograd derives for model/Feature_Grid_Model.py:62-75;
+ * triggered at training/training.py:137).  positions->pos must be non-NULL.
+ *   stash       device, written by the forward call with the same inputs
+ *   d_out       device (N)
+ *   d_grid_cl   device (D,H,W,Cs)  ACCUMULATED into with float atomics (caller zeroes it)
+ *   d_weights / d_biases  host arrays of L+1 device pointers, each OVERWRITTEN (same shapes as the
+ *               parameters)
+ *   d_pos       device (N,3) or NULL
+ *   workspace   device scratch of lfgc_backward_workspace_bytes() bytes */
+int64_t lfgc_backward_workspace_bytes(const lfgc_mlp_desc* desc, int64_t n_samples);
+int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
+                      const float* grid_cl, int D, int H, int W,
+                      const float* packed, const float* stash, const float* d_out,
+                      float* d_grid_cl, float* const* d_weights, float* const* d_biases, float* d_pos,
+                      void* workspace, int64_t workspace_bytes, lfgc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ground-truth sampler and volume statistics
+ * ---------------------------------------------------------------------------------------------- */
+
+/* trilinear_f_interpolation (data/Interpolation.py:8-44), bit-exact: fp32 lattice coordinates, fp64
+ * alpha, fp32 lerps in x, y, z order without contraction.
+ *   p device (N,3) raw positions; f device (X,Y,Z); min_bb/max_bb/res host float[3]; out device (N). */
+int lfgc_gt_interp_f32(const float* p, const float* f, const float* min_bb, const float* max_bb,
+                       const float* res, int64_t n, int X, int Y, int Z, float* out, lfgc_stream_t stream);
+
+/* Partial sums for calculate_deviation_statistics (visualization/OutputToVTK.py:53-60):
+ * acc[0] += sum (gt-pred)^2, acc[1] += sum |gt-pred|, acc[2] = min(acc[2], min gt), acc[3] = max(acc[3], max gt)
+ * over n elements, fp64 accumulators on device (caller initialises acc = {0, 0, +inf, -inf}). */
+int lfgc_deviation_partial_f32(const float* pred, const float* gt, int64_t n, double* acc, lfgc_stream_t stream);
+
+/* Diagnostics: evaluates the kernels' own sin/cos (Cody-Waite + polynomial, lfgc_common.h) and SnakeAlt
+ * on n device floats, fast path with the wave-level wide fallback exactly as the hot loops use them.
+ * Lets the tests bound the transcendental error against fp64 without going through a network. */
+int lfgc_debug_trig_f32(const float* x, int64_t n, float* sin_out, float* cos_out, float* snake_out,
+                        lfgc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFGC_H */

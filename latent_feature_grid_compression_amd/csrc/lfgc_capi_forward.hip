@@ -1,0 +1,81 @@
+// lfgc_capi_forward.hip -- C-ABI entry for the fused forward: argument checks, plan, dispatch.
+#include "lfgc_forward.h"
+
+int lfgc_fwd_dispatch_ch8(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+int lfgc_fwd_dispatch_ch16(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+int lfgc_fwd_dispatch_ch24(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+int lfgc_fwd_dispatch_ch32(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+
+namespace {
+int g_num_cus = 0;
+int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_num_cus = prop.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+}  // namespace
+
+// Validates `positions` and fills the position part of the kernel arguments; returns the sample count
+// through *n_out.
+int lfgc_fill_positions(const lfgc_positions* ps, LfgcFwdArgs* a, long long* n_out) {
+    if (!ps) return LFGC_E_NULL;
+    if (ps->pos) {
+        if (ps->n < 0) return LFGC_E_SHAPE;
+        a->pos = ps->pos;
+        *n_out = ps->n;
+        a->res0 = a->res1 = a->res2 = 2; a->x_begin = 0; a->tile = 32;
+        a->scale0 = a->scale1 = a->scale2 = 1.0f;
+        return LFGC_OK;
+    }
+    if (ps->res[0] < 2 || ps->res[1] < 2 || ps->res[2] < 2 || ps->tile < 1) return LFGC_E_SHAPE;
+    if (ps->x_begin < 0 || ps->x_end > ps->res[0] || ps->x_end < ps->x_begin) return LFGC_E_SHAPE;
+    if (ps->x_begin % ps->tile != 0) return LFGC_E_SHAPE;      // slabs start on a tile boundary
+    a->pos = nullptr;
+    a->res0 = ps->res[0]; a->res1 = ps->res[1]; a->res2 = ps->res[2];
+    a->x_begin = ps->x_begin; a->tile = ps->tile;
+    // dataset.scales = max_idx / max(max_idx)     (data/IndexDataset.py:64-65), fp32 division
+    const float m0 = (float)(ps->res[0] - 1), m1 = (float)(ps->res[1] - 1), m2 = (float)(ps->res[2] - 1);
+    const float mm = m0 > m1 ? (m0 > m2 ? m0 : m2) : (m1 > m2 ? m1 : m2);
+    a->scale0 = m0 / mm; a->scale1 = m1 / mm; a->scale2 = m2 / mm;
+    *n_out = (long long)(ps->x_end - ps->x_begin) * ps->res[1] * ps->res[2];
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
+                                const float* grid_cl, int D, int H, int W,
+                                const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream) {
+    if (!desc || !positions || !grid_cl || !packed || !out) return LFGC_E_NULL;
+    if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
+    if (D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
+    if ((((uintptr_t)grid_cl) | ((uintptr_t)packed)) & 15) return LFGC_E_ALIGN;
+    const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
+    LfgcFwdArgs a;
+    long long n = 0;
+    const int rc = lfgc_fill_positions(positions, &a, &n);
+    if (rc != LFGC_OK) return rc;
+    if (n == 0) return LFGC_OK;
+    a.n = n;
+    a.grid = grid_cl; a.D = D; a.H = H; a.W = W; a.Cs = p.CH;
+    a.packed = packed; a.L = p.L; a.clamp = clamp; a.out = out; a.stash = stash;
+    a.nbatches = (n + LFGC_WG_SAMPLES - 1) / LFGC_WG_SAMPLES;
+    // LDS: [Wf | bf] + either every layer block (resident, if two workgroups still fit a CU) or the largest one
+    const int all_blocks = p.off_final;
+    const int max_block = p.blk0 > p.blk1 ? p.blk0 : p.blk1;
+    a.resident = ((p.HP + 4 + all_blocks) * 4 <= 80 * 1024) ? 1 : 0;
+    const int lds_bytes = (p.HP + 4 + (a.resident ? all_blocks : max_block)) * 4;
+    long long grid = 2LL * num_cus();
+    if (grid > a.nbatches) grid = a.nbatches;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.CH) {
+        case 8: return lfgc_fwd_dispatch_ch8(p.MT, a, lds_bytes, (int)grid, st);
+        case 16: return lfgc_fwd_dispatch_ch16(p.MT, a, lds_bytes, (int)grid, st);
+        case 24: return lfgc_fwd_dispatch_ch24(p.MT, a, lds_bytes, (int)grid, st);
+        case 32: return lfgc_fwd_dispatch_ch32(p.MT, a, lds_bytes, (int)grid, st);
+        default: return LFGC_E_UNSUPPORTED;
+    }
+}

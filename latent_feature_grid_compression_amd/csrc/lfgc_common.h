@@ -1,0 +1,180 @@
+// lfgc_common.h -- shared device helpers and the packed-parameter plan (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lfgc.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LFGC_WAVE 64
+#define LFGC_TILE_SAMPLES 32          // samples per wave tile (N dimension of v_mfma_f32_32x32x2_f32)
+#define LFGC_WG_WAVES 4
+#define LFGC_WG_SAMPLES (LFGC_TILE_SAMPLES * LFGC_WG_WAVES)
+
+// ------------------------------------------------------------------------------------------------
+// Packed-parameter plan.  Everything is derived from the descriptor; host and device agree through
+// these constexpr-able formulas.
+//   CH   grid channels padded to 8            MT   hidden width in 32-row MFMA tiles
+//   E    scalar inputs 3 + 6*NF               EP   E padded to 8
+//   K0P  padded layer-0 fan-in = CH + EP      KS0  layer-0 k-steps = K0P/2 (one MFMA = 2 k values)
+//   HP   padded hidden = 32*MT                KS1  hidden k-steps = HP/2
+// Row strides carry +4 floats so that the 16 lanes of a ds_read_b128 group (distinct rows, same
+// column) fall on 16 distinct 16-byte bank slots (stride = 4 * odd).
+// Blob (floats):  [layer0: W (HP x S0) | bias HP] [layer l=1..L-1: W (HP x S1) | bias HP]
+//                 [final: Wf HP | bf 4]
+//                 [transposed copies for backward: layer0^T (K0P x ST) , layer l^T (HP x ST)]
+// ------------------------------------------------------------------------------------------------
+struct LfgcPlan {
+    int C, CH, H, HP, MT, L, NF, E, EP, K0P, KS0, KS1, S0, S1, ST;
+    int blk0, blk1;          // floats per forward layer block (weights + bias)
+    int off_final;           // float offset of [Wf | bf]
+    int fwd_floats;          // floats of the forward part
+    int tblk0, tblk1;        // floats per transposed block
+    int off_t;               // float offset of the transposed part
+    int total_floats;
+    int stash_tile_floats;   // floats saved per 32-sample tile: 64 * (KS0 + L*16*MT)
+};
+
+__host__ __device__ inline int lfgc_roundup(int v, int m) { return (v + m - 1) / m * m; }
+
+__host__ __device__ inline LfgcPlan lfgc_make_plan(int C, int H, int L, int NF) {
+    LfgcPlan p;
+    p.C = C; p.H = H; p.L = L; p.NF = NF;
+    p.CH = lfgc_roundup(C, 8);
+    p.HP = lfgc_roundup(H, 32);
+    if (p.HP == 96) p.HP = 128;          // compiled tile counts: MT in {1, 2, 4}
+    p.MT = p.HP / 32;
+    p.E = 3 + 6 * NF;
+    p.EP = lfgc_roundup(p.E, 8);
+    p.K0P = p.CH + p.EP;
+    p.KS0 = p.K0P / 2;
+    p.KS1 = p.HP / 2;
+    p.S0 = p.K0P + 4;
+    p.S1 = p.HP + 4;
+    p.ST = p.HP + 4;
+    p.blk0 = p.HP * p.S0 + p.HP;
+    p.blk1 = p.HP * p.S1 + p.HP;
+    p.off_final = p.blk0 + (L - 1) * p.blk1;
+    p.fwd_floats = p.off_final + p.HP + 4;
+    p.tblk0 = p.K0P * p.ST;
+    p.tblk1 = p.HP * p.ST;
+    p.off_t = p.fwd_floats;
+    p.total_floats = p.off_t + p.tblk0 + (L - 1) * p.tblk1;
+    p.stash_tile_floats = 64 * (p.KS0 + L * 16 * p.MT);
+    return p;
+}
+
+// Original nn.Linear column of layer 0 that packed column `cl` (0..K0P) holds, or -1 for padding.
+// Packed order: k-step s = cl/8*4 + cl%4, lane half hh = (cl/4)&1.  Steps s < CH/2 carry grid
+// channel hh*CH/2 + s; later steps carry scalar input hh*EP/2 + (s - CH/2) of
+// [p0 p1 p2 | sin f0 (3) cos f0 (3) | sin f1 ... ]  (model/Feature_Grid_Model.py:69 column order:
+// [input(3), embedding(6*NF), features(C)]).
+__host__ __device__ inline int lfgc_layer0_src_col(const LfgcPlan& p, int cl) {
+    const int s = (cl >> 3) * 4 + (cl & 3);
+    const int hh = (cl >> 2) & 1;
+    if (s < p.CH / 2) {
+        const int ch = hh * (p.CH / 2) + s;
+        return ch < p.C ? p.E + ch : -1;
+    }
+    const int e = hh * (p.EP / 2) + (s - p.CH / 2);
+    return e < p.E ? e : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sin / cos for the embedding and SnakeAlt: Cody-Waite reduction by pi (3 fp32 constants) to
+// r in [-pi/2, pi/2], then sin r = r + r^3 P(r^2), cos r = 1 + r^2 Q(r^2); max abs error 1.4e-7 for
+// |x| <= 2^15 (measured against fp64; tests/test_hip_kernels.py).  Outside that range (a diverged model) the
+// exact-reduction libm path is used.  The hardware v_sin_f32 (~1e-6 abs) is not accurate enough for
+// the 1e-5 end-to-end parity budget.
+// ------------------------------------------------------------------------------------------------
+#define LFGC_TRIG_FAST_MAX 32768.0f
+
+__device__ __forceinline__ float lfgc_reduce_pi_fast(float x, float& sign_bits) {
+    const float k = __builtin_rintf(x * 0.31830987334251404f);
+    float r = __builtin_fmaf(-k, 3.14159274101257324f, x);          // fp32(pi)
+    r = __builtin_fmaf(-k, -8.74227765734758577e-08f, r);           // fp32(pi - hi)
+    r = __builtin_fmaf(-k, -3.4302490200117637e-15f, r);            // fp32(pi - hi - mid)
+    const int ki = (int)k;
+    sign_bits = __int_as_float(ki << 31);                           // (-1)^k as a sign bit
+    return r;
+}
+
+// Rare path (|x| > 2^15, inf, nan): the same reduction carried in fp64 with a two-term pi; accurate to
+// fp32 rounding while k = rint(x/pi) is exact in fp64 (|x| < ~1e15), finite garbage in [-1,1] beyond,
+// NaN for inf/nan inputs like libm.
+__device__ __forceinline__ float lfgc_reduce_pi_wide(float x, float& sign_bits) {
+    const double xd = (double)x;
+    const double k = __builtin_rint(xd * 0.31830988618379067154);
+    double r = __builtin_fma(-k, 3.141592653589793116, xd);
+    r = __builtin_fma(-k, 1.2246467991473532072e-16, r);
+    const double half = k * 0.5;
+    sign_bits = (half != __builtin_floor(half)) ? -0.0f : 0.0f;
+    return (float)r;
+}
+
+// true when x must take the wide path (|x| > 2^15, inf or nan)
+__device__ __forceinline__ bool lfgc_trig_out_of_range(float x) { return !(__builtin_fabsf(x) <= LFGC_TRIG_FAST_MAX); }
+
+__device__ __forceinline__ float lfgc_sin_poly(float r) {
+    const float u = r * r;
+    float p = 2.6340962904214393e-06f;
+    p = __builtin_fmaf(p, u, -0.00019822562171611935f);
+    p = __builtin_fmaf(p, u, 0.008333241567015648f);
+    p = __builtin_fmaf(p, u, -0.1666666567325592f);
+    return __builtin_fmaf(r * u, p, r);
+}
+
+__device__ __forceinline__ float lfgc_cos_poly(float r) {
+    const float u = r * r;
+    float q = -2.628940194426832e-07f;
+    q = __builtin_fmaf(q, u, 2.47742427745834e-05f);
+    q = __builtin_fmaf(q, u, -0.0013888647081330419f);
+    q = __builtin_fmaf(q, u, 0.0416666604578495f);
+    q = __builtin_fmaf(q, u, -0.5f);
+    return __builtin_fmaf(u, q, 1.0f);
+}
+
+// WIDE = false: branch-free fast path (caller guarantees or separately checks the range);
+// WIDE = true : fp64 reduction, valid for every input.  Hot loops run the fast form on a whole tile and
+// redo the tile with the wide form under ONE wave-uniform branch if any lane was out of range, so the
+// MFMA/VALU stream is not cut into basic blocks per activation.
+template <bool WIDE>
+__device__ __forceinline__ float lfgc_sinf_t(float x) {
+    float sb;
+    const float r = WIDE ? lfgc_reduce_pi_wide(x, sb) : lfgc_reduce_pi_fast(x, sb);
+    return __int_as_float(__float_as_int(lfgc_sin_poly(r)) ^ __float_as_int(sb));
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void lfgc_sincosf_t(float x, float& s, float& c) {
+    float sb;
+    const float r = WIDE ? lfgc_reduce_pi_wide(x, sb) : lfgc_reduce_pi_fast(x, sb);
+    s = __int_as_float(__float_as_int(lfgc_sin_poly(r)) ^ __float_as_int(sb));
+    c = __int_as_float(__float_as_int(lfgc_cos_poly(r)) ^ __float_as_int(sb));
+}
+
+// SnakeAlt(a) = 0.5 a + sin(a)^2            (model/Feature_Grid_Model.py:12-13)
+template <bool WIDE>
+__device__ __forceinline__ float lfgc_snake_t(float a) {
+    const float s = lfgc_sinf_t<WIDE>(a);
+    return __builtin_fmaf(s, s, 0.5f * a);
+}
+
+// d SnakeAlt / da = 0.5 + 2 sin a cos a
+template <bool WIDE>
+__device__ __forceinline__ float lfgc_snake_grad_t(float a) {
+    float s, c;
+    lfgc_sincosf_t<WIDE>(a, s, c);
+    return __builtin_fmaf(2.0f * s, c, 0.5f);
+}
+
+// fp32 frequency f_k = fp32(2^k) * 2 * pi evaluated the way torch does for a float tensor
+// (model/Feature_Embedding.py:28-29): (2^k * 2) is exact, times fp32-rounded... torch multiplies the
+// fp32 tensor by the python double 2*pi?  No: `freq_bands * 2. * np.pi` = (t * 2.) * 3.14159..., each a
+// tensor-scalar multiply carried out in fp32 with the scalar cast to fp32 -> fp32(2^(k+1)) * fp32(pi).
+__device__ __forceinline__ float lfgc_freq(int k) {
+    return (float)(2 << k) * 3.14159274101257324f;     // exact power of two times fp32(pi): one rounding, exact here
+}
+
+#define LFGC_HIP_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -1,0 +1,319 @@
+// lfgc_forward.h -- fused trilinear sample + Fourier embed + SnakeAlt MLP forward for gfx950.
+//
+// Replaces model/Feature_Grid_Model.py:62-78 of the reference (grid_sample, Embedder.embed, cat,
+// L x (Linear + SnakeAlt), final Linear, optional clamp).
+//
+// Mapping (one wave = 32 samples, v_mfma_f32_32x32x2_f32, exact fp32):
+//   Out^T[h_out, sample] = W[h_out, k] . In^T[k, sample]
+//   A operand = W tile from LDS      lane (i = lane&31, hh = lane>>5) supplies W[32m + i][k(s, hh)]
+//   B operand = activations in VGPRs lane (j = lane&31, hh)           supplies In[k(s, hh)][sample j]
+//   C/D       = 16 accumulators      lane (j, hh), reg r = row 32m + (r&3) + 8(r>>2) + 4hh of sample j
+// The k order is chosen as k(s, hh) = 32(s>>4) + 8((s>>2)&3) + 4hh + (s&3), which is exactly the row a
+// lane's accumulator register r = s&15 of tile m = s>>4 holds: after SnakeAlt the accumulators ARE the
+// next layer's B operands, so activations never leave registers and never cross lanes.  With that
+// order a lane's A values for 4 consecutive k-steps are 4 consecutive floats of one W row: one
+// ds_read_b128 feeds 4 MFMAs.
+// Workgroup = 4 waves = 128 samples; weights are staged through LDS per layer (or once, if the whole
+// network fits), 2 workgroups per CU so one computes while the other stages.
+#pragma once
+#include "lfgc_common.h"
+
+struct LfgcFwdArgs {
+    const float* pos;          // (N,3) or nullptr (lattice mode)
+    long long n;               // samples
+    int res0, res1, res2;      // lattice mode: volume resolution
+    int x_begin;               // lattice mode: first x of the slab
+    int tile;                  // lattice mode: tile edge (32)
+    float scale0, scale1, scale2;   // lattice mode: dataset.scales (data/IndexDataset.py:64-65)
+    const float* grid;         // (D,H,W,Cs)
+    int D, H, W, Cs;
+    const float* packed;
+    int L;
+    int resident;              // 1: all layer blocks staged once
+    int clamp;
+    float* out;                // (N)
+    float* stash;              // or nullptr
+    long long nbatches;        // ceil(N / 128)
+};
+
+// Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile
+// (visualization/OutputToVTK.py:23-37) + torch.linspace's CPU formula (start + step*i below the
+// midpoint, end - step*(n-1-i) above).
+__device__ __forceinline__ float lfgc_lattice_coord(int v, int res, int tile, float scale) {
+    const int tb = (v / tile) * tile;
+    const int te = min(tb + tile, res);
+    const int cnt = te - tb;
+    const int i = v - tb;
+    const float max_idx = (float)(res - 1);
+    const float min_alpha = (float)((double)tb / (double)(res - 1));
+    const float max_alpha = (float)((double)(te - 1) / (double)(res - 1));
+    const float min_bounds = __fadd_rn(0.0f, __fmul_rn(min_alpha, max_idx));
+    const float max_bounds = __fadd_rn(0.0f, __fmul_rn(max_alpha, max_idx));
+    const float start = __fdiv_rn(min_bounds, max_idx);
+    const float end = __fdiv_rn(max_bounds, max_idx);
+    float lin;
+    if (cnt == 1) {
+        lin = start;
+    } else {
+        const float step = __fdiv_rn(__fsub_rn(end, start), (float)(cnt - 1));
+        lin = (i < cnt / 2) ? __fadd_rn(start, __fmul_rn(step, (float)i))
+                            : __fsub_rn(end, __fmul_rn(step, (float)(cnt - i - 1)));
+    }
+    const float nrm = __fsub_rn(__fmul_rn(2.0f, lin), 1.0f);
+    return __fmul_rn(scale, nrm);
+}
+
+// One hidden layer on a 32-sample tile held in registers.
+//   s_blk : LDS block [W (32*MT rows x S floats) | bias 32*MT]
+//   Bin   : KS activations of this lane (k order above);  Bout : 16*MT outputs (same order)
+//   stash : nullptr or this layer's slot for the tile: [(m*16 + r)][64 lanes]
+template <int KS, int MT, int S>
+__device__ __forceinline__ void lfgc_layer_fwd(const float* __restrict__ s_blk, const float (&Bin)[KS],
+                                               float (&Bout)[16 * MT], float* __restrict__ stash,
+                                               int j, int hh, int lane) {
+    static_assert(KS % 4 == 0, "k-steps come in groups of 4 (one ds_read_b128)");
+    const float* s_bias = s_blk + 32 * MT * S + 4 * hh;
+    const float* s_row = s_blk + j * S + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + 32 * m + 8 * q);
+            acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+        }
+        const float* arow = s_row + 32 * m * S;
+#pragma unroll
+        for (int qb = 0; qb < KS / 4; ++qb) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * qb);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, Bin[4 * qb + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, Bin[4 * qb + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, Bin[4 * qb + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, Bin[4 * qb + 3], acc, 0, 0, 0);
+        }
+        if (stash) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stash[(m * 16 + r) * 64 + lane] = acc[r];
+        }
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bad |= lfgc_trig_out_of_range(acc[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Bout[16 * m + r] = lfgc_snake_t<false>(acc[r]);
+        if (__builtin_expect(__any(bad), 0)) {       // wave-uniform; a diverged model only
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Bout[16 * m + r] = lfgc_snake_t<true>(acc[r]);
+        }
+    }
+}
+
+template <int CH, int MT, int NF>
+__global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
+    constexpr int E = 3 + 6 * NF;
+    constexpr int EP = (E + 7) / 8 * 8;
+    constexpr int K0P = CH + EP;
+    constexpr int KS0 = K0P / 2;
+    constexpr int HP = 32 * MT;
+    constexpr int KS1 = HP / 2;
+    constexpr int S0 = K0P + 4;
+    constexpr int S1 = HP + 4;
+    constexpr int BLK0 = HP * S0 + HP;
+    constexpr int BLK1 = HP * S1 + HP;
+    constexpr int CHH = CH / 2;          // channels gathered per lane
+    constexpr int EPH = EP / 2;          // scalar inputs carried per lane
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_final = smem;               // Wf (HP) | bf (4)
+    float* s_w = smem + HP + 4;          // layer blocks
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int j = lane & 31;
+    const int hh = lane >> 5;
+    const int L = a.L;
+    const int off_final = BLK0 + (L - 1) * BLK1;
+
+    {   // final layer (+ every layer block when resident): staged once per workgroup
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_final);
+        for (int i = tid; i < (HP + 4) / 4; i += 256) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
+        if (a.resident) {
+            const f32x4* srcw = reinterpret_cast<const f32x4*>(a.packed);
+            for (int i = tid; i < off_final / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = srcw[i];
+        }
+    }
+    __syncthreads();
+
+    const long long N = a.n;
+    for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
+        const long long tile_idx = batch * LFGC_WG_WAVES + wave;
+        const long long n = tile_idx * LFGC_TILE_SAMPLES + j;
+        const bool valid = n < N;
+        const long long nc = valid ? n : (N - 1);
+
+        // ---- positions ---------------------------------------------------------------------------
+        float p0, p1, p2;
+        if (a.pos) {
+            const float* pp = a.pos + 3 * nc;
+            p0 = pp[0]; p1 = pp[1]; p2 = pp[2];
+        } else {
+            const long long plane = (long long)a.res1 * a.res2;
+            const int vx = a.x_begin + (int)(nc / plane);
+            const int rem = (int)(nc % plane);
+            const int vy = rem / a.res2;
+            const int vz = rem % a.res2;
+            p0 = lfgc_lattice_coord(vx, a.res0, a.tile, a.scale0);
+            p1 = lfgc_lattice_coord(vy, a.res1, a.tile, a.scale1);
+            p2 = lfgc_lattice_coord(vz, a.res2, a.tile, a.scale2);
+        }
+
+        float B[(KS0 > KS1) ? KS0 : KS1];
+
+        // ---- trilinear gather: lane (j, hh) interpolates channels [hh*CHH, (hh+1)*CHH) -------------
+        {
+            // grid_sampler_unnormalize, align_corners=False: ((p + 1) * size - 1) / 2   (ATen GridSampler.h)
+            const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p0, 1.0f), (float)a.W), 1.0f), 2.0f);
+            const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p1, 1.0f), (float)a.H), 1.0f), 2.0f);
+            const float iz = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p2, 1.0f), (float)a.D), 1.0f), 2.0f);
+            const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+            // clamp before the int conversion so absurd positions stay defined (they get weight 0 anyway)
+            const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)a.W);
+            const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)a.H);
+            const int z0 = (int)fminf(fmaxf(fz0, -2.0f), (float)a.D);
+            const float wx1 = __fsub_rn(ix, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+            const float wy1 = __fsub_rn(iy, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+            const float wz1 = __fsub_rn(iz, fz0), wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
+            const bool in_range = (fx0 >= -1.0f) && (fx0 < (float)a.W) && (fy0 >= -1.0f) && (fy0 < (float)a.H) &&
+                                  (fz0 >= -1.0f) && (fz0 < (float)a.D);
+            float feat[CHH];
+#pragma unroll
+            for (int c = 0; c < CHH; ++c) feat[c] = 0.0f;
+            const float* gbase = a.grid + hh * CHH;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const int dz = corner >> 2, dy = (corner >> 1) & 1, dx = corner & 1;   // ATen order: tnw, tne, tsw, tse, bnw, ...
+                const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+                const bool ok = in_range && xi >= 0 && xi < a.W && yi >= 0 && yi < a.H && zi >= 0 && zi < a.D;
+                float w = __fmul_rn(__fmul_rn(dx ? wx1 : wx0, dy ? wy1 : wy0), dz ? wz1 : wz0);
+                w = ok ? w : 0.0f;
+                const int xc = min(max(xi, 0), a.W - 1), yc = min(max(yi, 0), a.H - 1), zc = min(max(zi, 0), a.D - 1);
+                const float* gp = gbase + ((long long)(zc * a.H + yc) * a.W + xc) * a.Cs;
+#pragma unroll
+                for (int c4 = 0; c4 < CHH / 4; ++c4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(gp + 4 * c4);
+                    feat[4 * c4 + 0] = __builtin_fmaf(v.x, w, feat[4 * c4 + 0]);
+                    feat[4 * c4 + 1] = __builtin_fmaf(v.y, w, feat[4 * c4 + 1]);
+                    feat[4 * c4 + 2] = __builtin_fmaf(v.z, w, feat[4 * c4 + 2]);
+                    feat[4 * c4 + 3] = __builtin_fmaf(v.w, w, feat[4 * c4 + 3]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CHH; ++c) B[c] = feat[c];
+        }
+
+        // ---- scalar inputs [p | sin f_k p | cos f_k p]: every lane evaluates all, keeps its half -----
+        {
+            float e[EP];
+            e[0] = p0; e[1] = p1; e[2] = p2;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const float f = lfgc_freq(k);
+                const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f);
+                bad |= lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2);
+                float s, c;
+                lfgc_sincosf_t<false>(a0, s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
+                lfgc_sincosf_t<false>(a1, s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
+                lfgc_sincosf_t<false>(a2, s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
+            }
+            if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    const float f = lfgc_freq(k);
+                    float s, c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p0, f), s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p1, f), s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p2, f), s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
+                }
+            }
+#pragma unroll
+            for (int t = E; t < EP; ++t) e[t] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < EPH; ++t) {
+                float lo = e[t], hi = e[EPH + t];
+                asm volatile("" : "+v"(lo), "+v"(hi));     // keep both in VGPRs: a select of two array slots would go to scratch
+                B[CHH + t] = hh ? hi : lo;
+            }
+        }
+
+        float* stash_tile = nullptr;
+        if (a.stash) {
+            stash_tile = a.stash + tile_idx * (long long)(64 * (KS0 + L * 16 * MT));
+#pragma unroll
+            for (int s = 0; s < KS0; ++s) stash_tile[s * 64 + lane] = B[s];
+            stash_tile += 64 * KS0;
+        }
+
+        // ---- layer 0 -------------------------------------------------------------------------------
+        float Bn[16 * MT];
+        {
+            if (!a.resident) {
+                __syncthreads();                         // previous batch done with the buffer
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
+                for (int i = tid; i < BLK0 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+                __syncthreads();
+            }
+            float B0[KS0];
+#pragma unroll
+            for (int s = 0; s < KS0; ++s) B0[s] = B[s];
+            lfgc_layer_fwd<KS0, MT, S0>(s_w, B0, Bn, stash_tile, j, hh, lane);
+        }
+        // ---- hidden layers 1..L-1 --------------------------------------------------------------------
+        for (int l = 1; l < L; ++l) {
+            const float* blk;
+            if (a.resident) {
+                blk = s_w + BLK0 + (l - 1) * BLK1;
+            } else {
+                __syncthreads();
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + BLK0 + (long long)(l - 1) * BLK1);
+                for (int i = tid; i < BLK1 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+                __syncthreads();
+                blk = s_w;
+            }
+            float Bi[KS1];
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) Bi[s] = Bn[s];
+            lfgc_layer_fwd<KS1, MT, S1>(blk, Bi, Bn, stash_tile ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr,
+                                        j, hh, lane);
+        }
+
+        // ---- final Linear (H -> 1): per-lane partial dot + exchange between the two lane halves ------
+        float y = 0.0f;
+#pragma unroll
+        for (int qb = 0; qb < KS1 / 4; ++qb) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_final + 8 * qb + 4 * hh);
+            y = __builtin_fmaf(w4.x, Bn[4 * qb + 0], y);
+            y = __builtin_fmaf(w4.y, Bn[4 * qb + 1], y);
+            y = __builtin_fmaf(w4.z, Bn[4 * qb + 2], y);
+            y = __builtin_fmaf(w4.w, Bn[4 * qb + 3], y);
+        }
+        y += __shfl_xor(y, 32);
+        y += s_final[HP];
+        if (a.clamp) y = fminf(fmaxf(y, -1.0f), 1.0f);
+        if (valid && hh == 0) a.out[n] = y;
+    }
+}
+
+// Host-side launcher for one instantiation.
+template <int CH, int MT, int NF>
+static int lfgc_launch_fwd(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
+    auto kern = lfgc_fwd_kernel<CH, MT, NF>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}

@@ -1,0 +1,259 @@
+// lfgc_misc.hip -- ground-truth sampler, deviation statistics, parameter packing (gfx950).
+#include "lfgc_common.h"
+#include <math.h>
+
+namespace {
+
+struct GtArgs {
+    const float* p; const float* f; float* out; long long n;
+    int X, Y, Z;
+    float min0, min1, min2, max0, max1, max2, res0, res1, res2;
+};
+
+// data/Interpolation.py:8-44, same operation order, no contraction (file is built with -ffp-contract=off
+// and the arithmetic below uses the explicit round-to-nearest intrinsics).
+__global__ __launch_bounds__(256) void gt_interp_kernel(const GtArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const float px = a.p[3 * i + 0], py = a.p[3 * i + 1], pz = a.p[3 * i + 2];
+    // normalized_p = ((p - min_bb) / (max_bb - min_bb)) * (res - 1)
+    const float nx = __fmul_rn(__fdiv_rn(__fsub_rn(px, a.min0), __fsub_rn(a.max0, a.min0)), __fsub_rn(a.res0, 1.0f));
+    const float ny = __fmul_rn(__fdiv_rn(__fsub_rn(py, a.min1), __fsub_rn(a.max1, a.min1)), __fsub_rn(a.res1, 1.0f));
+    const float nz = __fmul_rn(__fdiv_rn(__fsub_rn(pz, a.min2), __fsub_rn(a.max2, a.min2)), __fsub_rn(a.res2, 1.0f));
+    const float flx = floorf(nx), fly = floorf(ny), flz = floorf(nz);
+    const float cex = ceilf(nx), cey = ceilf(ny), cez = ceilf(nz);
+    long long x0 = (long long)flx, y0 = (long long)fly, z0 = (long long)flz;
+    long long x1 = (long long)cex, y1 = (long long)cey, z1 = (long long)cez;
+    // alpha = (normalized_p - floor) / max(ceil - floor, 1e-12)  in fp64, then cast to fp32
+    const double min_ref = (double)1e-12f;        // 1e-12 * ones (fp32 tensor) -> .to(double)
+    const float ax = (float)(((double)nx - (double)x0) / fmax((double)(x1 - x0), min_ref));
+    const float ay = (float)(((double)ny - (double)y0) / fmax((double)(y1 - y0), min_ref));
+    const float az = (float)(((double)nz - (double)z0) / fmax((double)(z1 - z0), min_ref));
+    const float bx = __fsub_rn(1.0f, ax), by = __fsub_rn(1.0f, ay), bz = __fsub_rn(1.0f, az);
+    // torch advanced indexing wraps negative indices and raises on out-of-range; positions here are
+    // lattice coordinates inside the volume (data/IndexDataset.py:91), so indices are clamped defensively.
+    auto cl = [](long long v, int n) { return (int)(v < 0 ? 0 : (v >= n ? n - 1 : v)); };
+    const int X0 = cl(x0, a.X), X1 = cl(x1, a.X), Y0 = cl(y0, a.Y), Y1 = cl(y1, a.Y), Z0 = cl(z0, a.Z), Z1 = cl(z1, a.Z);
+    auto F = [&](int x, int y, int z) { return a.f[((long long)x * a.Y + y) * a.Z + z]; };
+    const float x_y0z0 = __fadd_rn(__fmul_rn(bx, F(X0, Y0, Z0)), __fmul_rn(ax, F(X1, Y0, Z0)));
+    const float x_y1z0 = __fadd_rn(__fmul_rn(bx, F(X0, Y1, Z0)), __fmul_rn(ax, F(X1, Y1, Z0)));
+    const float x_y0z1 = __fadd_rn(__fmul_rn(bx, F(X0, Y0, Z1)), __fmul_rn(ax, F(X1, Y0, Z1)));
+    const float x_y1z1 = __fadd_rn(__fmul_rn(bx, F(X0, Y1, Z1)), __fmul_rn(ax, F(X1, Y1, Z1)));
+    const float y_z0 = __fadd_rn(__fmul_rn(by, x_y0z0), __fmul_rn(ay, x_y1z0));
+    const float y_z1 = __fadd_rn(__fmul_rn(by, x_y0z1), __fmul_rn(ay, x_y1z1));
+    a.out[i] = __fadd_rn(__fmul_rn(bz, y_z0), __fmul_rn(az, y_z1));
+}
+
+__device__ __forceinline__ void atomic_min_double(double* addr, double v) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = *p;
+    while (__longlong_as_double((long long)old) > v) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(p, assumed, (unsigned long long)__double_as_longlong(v));
+        if (old == assumed) break;
+    }
+}
+__device__ __forceinline__ void atomic_max_double(double* addr, double v) {
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = *p;
+    while (__longlong_as_double((long long)old) < v) {
+        const unsigned long long assumed = old;
+        old = atomicCAS(p, assumed, (unsigned long long)__double_as_longlong(v));
+        if (old == assumed) break;
+    }
+}
+
+// visualization/OutputToVTK.py:53-60 partial sums (fp64 accumulation).
+__global__ __launch_bounds__(256) void deviation_kernel(const float* pred, const float* gt, long long n, double* acc) {
+    double sq = 0.0, ab = 0.0, mn = INFINITY, mx = -INFINITY;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float g = gt[i];
+        const float d = __fsub_rn(g, pred[i]);
+        sq += (double)d * (double)d;
+        ab += fabs((double)d);
+        mn = fmin(mn, (double)g);
+        mx = fmax(mx, (double)g);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sq += __shfl_down(sq, off);
+        ab += __shfl_down(ab, off);
+        mn = fmin(mn, __shfl_down(mn, off));
+        mx = fmax(mx, __shfl_down(mx, off));
+    }
+    __shared__ double s[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s[wave][0] = sq; s[wave][1] = ab; s[wave][2] = mn; s[wave][3] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { sq += s[w][0]; ab += s[w][1]; mn = fmin(mn, s[w][2]); mx = fmax(mx, s[w][3]); }
+        atomicAdd(&acc[0], sq);
+        atomicAdd(&acc[1], ab);
+        atomic_min_double(&acc[2], mn);
+        atomic_max_double(&acc[3], mx);
+    }
+}
+
+__global__ __launch_bounds__(256) void debug_trig_kernel(const float* x, long long n, float* so, float* co, float* sn) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const float v = x[i < n ? i : n - 1];
+    float s, c, k;
+    lfgc_sincosf_t<false>(v, s, c);
+    k = lfgc_snake_t<false>(v);
+    if (__any(lfgc_trig_out_of_range(v))) {
+        lfgc_sincosf_t<true>(v, s, c);
+        k = lfgc_snake_t<true>(v);
+    }
+    if (i < n) { so[i] = s; co[i] = c; sn[i] = k; }
+}
+
+struct PackArgs {
+    const float* w[LFGC_MAX_LAYERS + 1];
+    const float* b[LFGC_MAX_LAYERS + 1];
+    float* packed;
+    LfgcPlan plan;
+};
+
+// Re-lay nn.Linear parameters into the blob described in lfgc_common.h.
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
+    const LfgcPlan& p = a.plan;
+    const int K0 = p.E + p.C;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < p.total_floats; idx += gridDim.x * 256) {
+        float v = 0.0f;
+        if (idx < p.blk0) {                                   // layer 0: permuted columns
+            if (idx < p.HP * p.S0) {
+                const int row = idx / p.S0, cl = idx % p.S0;
+                if (row < p.H && cl < p.K0P) {
+                    const int src = lfgc_layer0_src_col(p, cl);
+                    if (src >= 0) v = a.w[0][row * K0 + src];
+                }
+            } else {
+                const int r = idx - p.HP * p.S0;
+                if (r < p.H) v = a.b[0][r];
+            }
+        } else if (idx < p.off_final) {                       // hidden layers: natural columns
+            const int l = 1 + (idx - p.blk0) / p.blk1;
+            const int o = (idx - p.blk0) % p.blk1;
+            if (o < p.HP * p.S1) {
+                const int row = o / p.S1, cl = o % p.S1;
+                if (row < p.H && cl < p.H) v = a.w[l][row * p.H + cl];
+            } else {
+                const int r = o - p.HP * p.S1;
+                if (r < p.H) v = a.b[l][r];
+            }
+        } else if (idx < p.fwd_floats) {                      // final layer
+            const int o = idx - p.off_final;
+            if (o < p.H) v = a.w[p.L][o];
+            else if (o == p.HP) v = a.b[p.L][0];
+        } else if (idx < p.off_t + p.tblk0) {                 // layer 0 transposed: [packed col][h_out]
+            const int o = idx - p.off_t;
+            const int cl = o / p.ST, ho = o % p.ST;
+            if (ho < p.H) {
+                const int src = lfgc_layer0_src_col(p, cl);
+                if (src >= 0) v = a.w[0][ho * K0 + src];
+            }
+        } else {                                              // hidden layers transposed: [k_in][h_out]
+            const int o = idx - p.off_t - p.tblk0;
+            const int l = 1 + o / p.tblk1;
+            const int oo = o % p.tblk1;
+            const int ki = oo / p.ST, ho = oo % p.ST;
+            if (ki < p.H && ho < p.H) v = a.w[l][ho * p.H + ki];
+        }
+        a.packed[idx] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int lfgc_gt_interp_f32(const float* p, const float* f, const float* min_bb, const float* max_bb,
+                                  const float* res, int64_t n, int X, int Y, int Z, float* out, lfgc_stream_t stream) {
+    if (!p || !f || !min_bb || !max_bb || !res || !out) return LFGC_E_NULL;
+    if (n < 0 || X < 1 || Y < 1 || Z < 1) return LFGC_E_SHAPE;
+    if (n == 0) return LFGC_OK;
+    GtArgs a;
+    a.p = p; a.f = f; a.out = out; a.n = n; a.X = X; a.Y = Y; a.Z = Z;
+    a.min0 = min_bb[0]; a.min1 = min_bb[1]; a.min2 = min_bb[2];
+    a.max0 = max_bb[0]; a.max1 = max_bb[1]; a.max2 = max_bb[2];
+    a.res0 = res[0]; a.res1 = res[1]; a.res2 = res[2];
+    hipLaunchKernelGGL(gt_interp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_deviation_partial_f32(const float* pred, const float* gt, int64_t n, double* acc, lfgc_stream_t stream) {
+    if (!pred || !gt || !acc) return LFGC_E_NULL;
+    if (n < 0) return LFGC_E_SHAPE;
+    if (n == 0) return LFGC_OK;
+    long long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(deviation_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, pred, gt, (long long)n, acc);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_mlp_supported(const lfgc_mlp_desc* d) {
+    if (!d) return 0;
+    if (d->d_in != 3 || d->d_out != 1) return 0;
+    if (d->grid_channels < 1 || d->grid_channels > 32) return 0;
+    if (d->hidden < 1 || d->hidden > 128) return 0;
+    if (d->num_layers < 1 || d->num_layers > LFGC_MAX_LAYERS) return 0;
+    if (d->n_freqs != 2) return 0;
+    return 1;
+}
+
+extern "C" int lfgc_grid_channel_stride(int C) { return lfgc_roundup(C, 8); }
+
+extern "C" int64_t lfgc_packed_bytes(const lfgc_mlp_desc* d) {
+    if (!lfgc_mlp_supported(d)) return LFGC_E_UNSUPPORTED;
+    return (int64_t)lfgc_make_plan(d->grid_channels, d->hidden, d->num_layers, d->n_freqs).total_floats * 4;
+}
+
+extern "C" int64_t lfgc_stash_bytes(const lfgc_mlp_desc* d, int64_t n) {
+    if (!lfgc_mlp_supported(d)) return LFGC_E_UNSUPPORTED;
+    if (n < 0) return LFGC_E_SHAPE;
+    const LfgcPlan p = lfgc_make_plan(d->grid_channels, d->hidden, d->num_layers, d->n_freqs);
+    const int64_t tiles = (n + LFGC_WG_SAMPLES - 1) / LFGC_WG_SAMPLES * LFGC_WG_WAVES;   // whole workgroup batches
+    return tiles * (int64_t)p.stash_tile_floats * 4;
+}
+
+extern "C" int lfgc_pack_mlp_f32(const lfgc_mlp_desc* d, const float* const* weights, const float* const* biases,
+                                 float* packed, lfgc_stream_t stream) {
+    if (!d || !weights || !biases || !packed) return LFGC_E_NULL;
+    if (!lfgc_mlp_supported(d)) return LFGC_E_UNSUPPORTED;
+    if (((uintptr_t)packed) & 15) return LFGC_E_ALIGN;
+    PackArgs a;
+    a.plan = lfgc_make_plan(d->grid_channels, d->hidden, d->num_layers, d->n_freqs);
+    for (int l = 0; l <= d->num_layers; ++l) {
+        if (!weights[l] || !biases[l]) return LFGC_E_NULL;
+        a.w[l] = weights[l];
+        a.b[l] = biases[l];
+    }
+    a.packed = packed;
+    const int g = (a.plan.total_floats + 255) / 256;
+    hipLaunchKernelGGL(pack_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_debug_trig_f32(const float* x, int64_t n, float* sin_out, float* cos_out, float* snake_out,
+                                   lfgc_stream_t stream) {
+    if (!x || !sin_out || !cos_out || !snake_out) return LFGC_E_NULL;
+    if (n <= 0) return n == 0 ? LFGC_OK : LFGC_E_SHAPE;
+    hipLaunchKernelGGL(debug_trig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, (long long)n, sin_out, cos_out, snake_out);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_version(void) { return LFGC_VERSION; }
+
+extern "C" const char* lfgc_error_string(int code) {
+    switch (code) {
+        case LFGC_OK: return "ok";
+        case LFGC_E_NULL: return "required pointer is NULL";
+        case LFGC_E_SHAPE: return "invalid or inconsistent extent";
+        case LFGC_E_UNSUPPORTED: return "network shape outside the compiled kernel set";
+        case LFGC_E_ALIGN: return "pointer must be 16-byte aligned";
+        case LFGC_E_WORKSPACE: return "workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown lfgc error";
+    }
+}

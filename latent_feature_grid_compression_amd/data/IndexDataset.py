@@ -1,0 +1,57 @@
+"""Host-side lattice bookkeeping the drivers need: mirror of the arithmetic in data/IndexDataset.py
+(normalize_volume :7-8, IndexDataset.__init__ :51-65, generate_indices :69-76, __getitem__ :90-96).
+File loaders (.npy/.h5/.cvol) are out of scope; volumes are handed over as tensors."""
+from __future__ import annotations
+
+import torch
+
+
+def normalize_volume(volume, minV, maxV, minN, maxN):
+    return (maxN - minN) * ((volume - minV) / (maxV - minV)) + minN
+
+
+def normalize_to_unit_range(volume: torch.Tensor) -> torch.Tensor:
+    """get_tensor_from_numpy's normalisation (:15-17): min-max to [-1, 1]."""
+    return normalize_volume(volume, torch.min(volume), torch.max(volume), -1.0, 1.0)
+
+
+class IndexDataset(torch.utils.data.Dataset):
+    def __init__(self, volume, sampleSize=16, build_index_table=True):
+        shape = tuple(int(v) for v in (volume.shape if hasattr(volume, 'shape') else volume))
+        self.vol_res = torch.tensor(shape, dtype=torch.float)
+        self.vol_res_touple = shape
+        self.n_voxels = int(shape[0]) * int(shape[1]) * int(shape[2])
+        self.min_idx = torch.tensor([0.0, 0.0, 0.0], dtype=torch.float)
+        self.max_idx = torch.tensor([self.vol_res[0] - 1, self.vol_res[1] - 1, self.vol_res[2] - 1], dtype=torch.float)
+        # the reference materialises an (n_voxels, 3) table (12.9 GB at 1024^3); optional here
+        self.volume_indices = (self.generate_indices(self.min_idx, self.max_idx, self.vol_res.int()).view(-1, 3)
+                               if build_index_table else None)
+        self.sample_size = sampleSize
+        self.max_dim = torch.max(self.max_idx)
+        self.scales = self.max_idx / self.max_dim
+
+    def generate_indices(self, start, end, res):
+        r = [int(v) for v in res]
+        out = torch.zeros(r[0], r[1], r[2], 3)
+        out[:, :, :, 0] = torch.linspace(float(start[0]), float(end[0]), r[0], dtype=torch.float).view(r[0], 1, 1)
+        out[:, :, :, 1] = torch.linspace(float(start[1]), float(end[1]), r[1], dtype=torch.float).view(1, r[1], 1)
+        out[:, :, :, 2] = torch.linspace(float(start[2]), float(end[2]), r[2], dtype=torch.float).view(1, 1, r[2])
+        return out
+
+    def lattice_from_flat(self, flat_idx: torch.Tensor) -> torch.Tensor:
+        """Rows of the index table without materialising it."""
+        _, Y, Z = self.vol_res_touple
+        return torch.stack([flat_idx // (Y * Z), (flat_idx // Z) % Y, flat_idx % Z], -1).to(torch.float)
+
+    def positions_for(self, raw: torch.Tensor):
+        norm = normalize_volume(raw, self.min_idx.to(raw.device).unsqueeze(0), self.max_idx.to(raw.device).unsqueeze(0),
+                                -1.0, 1.0)
+        return raw, self.scales.to(raw.device).unsqueeze(0) * norm
+
+    def __len__(self):
+        return self.n_voxels
+
+    def __getitem__(self, index):
+        flat = torch.randint(0, self.n_voxels, (self.sample_size,))
+        raw = self.volume_indices[flat] if self.volume_indices is not None else self.lattice_from_flat(flat)
+        return self.positions_for(raw)

@@ -1,0 +1,171 @@
+"""Drop-in for the reference's model/Feature_Grid_Model.py (class Feature_Grid_Model :16-140).
+
+Same constructor, ``forward(input)`` signature, attribute names, parameter names/order and state_dict
+keys, so it slots into Feature_Grid_Training.py / Feature_Grid_Inference.py in place of the original.
+What differs is where the arithmetic runs: ``forward`` = HIP inverse-wavelet decode of the latent grid
+(channel-last, cached while the parameters do not change in eval mode) + ONE fused HIP kernel for
+trilinear sampling, Fourier embedding and the SnakeAlt MLP, with hand-written HIP backward kernels
+behind ``torch.autograd.Function``.  There is no CPU path: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..wavelet_transform.Torch_Wavelet_Transform import _WaveletFilterNd, dwt_max_level
+from .Feature_Embedding import Embedder
+
+
+def SnakeAlt(x):
+    return 0.5 * x + torch.sin(x) ** 2
+
+
+class Feature_Grid_Model(nn.Module):
+    def __init__(self, embedder: Embedder, feature_grid, drop_layer, wavelet_filter: _WaveletFilterNd,
+                 input_channel_data=3, hidden_channel=32, out_channel=1, num_layer=4, num_levels=None):
+        super().__init__()
+        self.embedder = embedder
+        self.filter = wavelet_filter
+
+        features, shapes = self.encode_volume(feature_grid, num_levels=num_levels)
+        self.feature_grid = nn.ParameterList([nn.Parameter(f, requires_grad=True) for f in features])
+        self.shape_array = shapes
+
+        if drop_layer is None:
+            self.drop = nn.ModuleList([nn.Identity() for _ in features])
+        else:
+            self.drop = nn.ModuleList([drop_layer.create_instance(f.shape[1:], drop_layer.p, drop_layer.threshold)
+                                       for f in features])
+
+        self.input_channel = input_channel_data + embedder.out_dim + feature_grid.shape[0]
+        self.hidden_width = hidden_channel
+        self.output_channel = out_channel
+        self.num_layer = num_layer
+        self.d_in = input_channel_data
+        self.grid_channels = int(feature_grid.shape[0])
+        n_freqs = getattr(embedder, 'n_freqs', None)
+        if n_freqs is None:
+            n_freqs = embedder.out_dim // (2 * input_channel_data)
+        self.n_freqs = int(n_freqs)
+
+        self.net_layers = nn.ModuleList(
+            [nn.Linear(self.input_channel, self.hidden_width)] +
+            [nn.Linear(self.hidden_width, self.hidden_width) for _ in range(self.num_layer - 1)])
+        self.final_layer = nn.Linear(self.hidden_width, self.output_channel)
+
+        self._grid_cache = None      # (key, channel-last dense grid) while parameters are unchanged (eval)
+        self._pack_cache = None      # (key, packed MLP blob)
+        self._desc = None
+
+    # ---- host-side keys for the caches: (data_ptr, in-place version) of every tensor involved -----------
+    @staticmethod
+    def _key(tensors) -> tuple:
+        return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors)
+
+    def _mlp_params(self):
+        layers = list(self.net_layers) + [self.final_layer]
+        return [l.weight for l in layers], [l.bias for l in layers]
+
+    def _descriptor(self):
+        if self._desc is None:
+            self._desc = ops.make_desc(self.grid_channels, self.hidden_width, self.num_layer, self.n_freqs,
+                                       self.d_in, self.output_channel)
+        return self._desc
+
+    def _packed(self) -> torch.Tensor:
+        weights, biases = self._mlp_params()
+        key = self._key(weights + biases)
+        if self._pack_cache is None or self._pack_cache[0] != key:
+            self._pack_cache = (key, ops.pack_mlp(self._descriptor(), weights, biases))
+        return self._pack_cache[1]
+
+    def _identity_drop(self) -> bool:
+        return all(isinstance(d, nn.Identity) for d in self.drop)
+
+    def _decoded_channel_last(self) -> torch.Tensor:
+        """decode_volume() in the sampler's layout (G,G,G,Cs).  Differentiable when grads are enabled;
+        cached across calls in no-grad mode while no coefficient changed (the reference re-decodes the
+        whole grid for every 32^3 tile, visualization/OutputToVTK.py:41)."""
+        track = torch.is_grad_enabled() and any(p.requires_grad for p in self.feature_grid)
+        cacheable = (not track) and self._identity_drop()
+        key = self._key(list(self.feature_grid) + [self.filter.filter_rev]) if cacheable else None
+        if cacheable and self._grid_cache is not None and self._grid_cache[0] == key:
+            return self._grid_cache[1]
+        coeffs = [d(g) for g, d in zip(self.feature_grid, self.drop)]
+        if track or any(c.requires_grad for c in coeffs):
+            grid = ops.DecodeVolumeFn.apply(self.filter.filter_rev, self.shape_array, True,
+                                            *[c.contiguous() for c in coeffs])
+        else:
+            grid = ops.decode_levels(coeffs, self.shape_array, self.filter.filter_rev, channel_last=True)
+        if cacheable:
+            self._grid_cache = (key, grid)
+        return grid
+
+    def forward(self, input):
+        grid_cl = self._decoded_channel_last()
+
+        orig_shape = input.shape
+        if not self.training:
+            # reference :57-60 flattens the tile with squeeze()/view (which breaks on size-1 axes and, on
+            # torch >= 2, at :78); the intended semantics are implemented: flatten, run, restore, clamp.
+            input = input.reshape(-1, orig_shape[-1])
+        if input.dim() != 2 or input.shape[-1] != self.d_in:
+            raise ValueError('expected positions of shape (N, %d), got %s' % (self.d_in, tuple(orig_shape)))
+
+        weights, biases = self._mlp_params()
+        x = ops.SampleDecodeFn.apply(self._descriptor(), input, grid_cl, self._packed(), self.num_layer,
+                                     *weights, *biases)
+
+        if not self.training:
+            x = x.view(*orig_shape[:-1], 1).clamp(-1, 1)
+        return x
+
+    # ---- wavelet representation of the grid (reference :83-108) ------------------------------------------
+    def encode_volume(self, feature_volume, num_levels=None):
+        if num_levels is None:
+            num_levels = min(dwt_max_level(s, self.filter.filter_length) for s in feature_volume.shape[-3:])
+        features, shapes = [], []
+        data = feature_volume.detach().unsqueeze(0)
+        for _ in range(num_levels):
+            filtered, shape = self.filter.encode(data)
+            features.append(filtered[0, :, 1:])
+            shapes.append(shape)
+            data = filtered[:, :, 0]
+        features = [data[0]] + [*reversed(features)]
+        shape_array = np.asarray(shapes[::-1], dtype=int)
+        return features, shape_array
+
+    def decode_volume(self) -> torch.Tensor:
+        """Dense grid (C,G,G,G), channel-first like the reference's decode_volume()."""
+        coeffs = [d(g).contiguous() for g, d in zip(self.feature_grid, self.drop)]
+        if torch.is_grad_enabled() and any(c.requires_grad for c in coeffs):
+            return ops.DecodeVolumeFn.apply(self.filter.filter_rev, self.shape_array, False, *coeffs)
+        return ops.decode_levels(coeffs, self.shape_array, self.filter.filter_rev, channel_last=False)
+
+    # ---- pruning bookkeeping (reference :110-140): pure tensor logic on the drop layers' own methods ------
+    def save_dropvalues_on_grid(self, device):
+        if isinstance(self.drop[0], nn.Identity):
+            return torch.tensor(0, dtype=torch.float32)
+        f_grid = [d.multiply_values_with_dropout(grid, device) for grid, d in zip(self.feature_grid, self.drop)]
+        self.feature_grid = nn.ParameterList([nn.Parameter(f, requires_grad=True) for f in f_grid])
+        zeros = 0
+        for grid in f_grid:
+            zeros += (grid.numel() - torch.count_nonzero(grid))
+        binary_mask_in_floats = torch.tensor(0, dtype=torch.float32)
+        for d in self.drop:
+            binary_mask_in_floats += d.size_layer()
+        return zeros - binary_mask_in_floats / 32.0
+
+    def remove_drop_layers(self, device):
+        binary_masks = []
+        for dropl in self.drop:
+            if isinstance(dropl, nn.Identity):
+                return
+            binary_masks.append(dropl.calculate_pruning_mask(device))
+        f_grid = [grid * mask for grid, mask in zip(self.feature_grid, binary_masks)]
+        self.feature_grid = nn.ParameterList([nn.Parameter(f, requires_grad=True) for f in f_grid])
+        self.drop = nn.ModuleList([nn.Identity() for _ in self.drop])

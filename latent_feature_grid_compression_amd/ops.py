@@ -1,0 +1,265 @@
+"""Tensor-level wrappers over the C-ABI (device memory and streams come from PyTorch-ROCm; all
+arithmetic happens in liblfgc.so) and the two autograd Functions of the hot path."""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MlpDesc, Positions, check
+
+
+def _require_hip(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.LfgcError('the latent-feature-grid hot path runs on the MI355X only: got a %s tensor. '
+                                 'Move the module and its inputs to the GPU (model.cuda()); there is no CPU fallback.'
+                                 % t.device)
+
+
+def _stream(t: torch.Tensor) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def make_desc(C: int, H: int, L: int, n_freqs: int, d_in: int = 3, d_out: int = 1) -> MlpDesc:
+    d = MlpDesc(int(C), int(H), int(L), int(n_freqs), int(d_in), int(d_out))
+    if not _lib.load().lfgc_mlp_supported(ctypes.byref(d)):
+        raise _lib.LfgcError('network shape not covered by the compiled HIP kernels: grid_channels=%d (<=32), hidden=%d '
+                             '(<=128), num_layer=%d (<=8), n_freqs=%d (==2), d_in=%d (==3), d_out=%d (==1)'
+                             % (C, H, L, n_freqs, d_in, d_out))
+    return d
+
+
+def grid_channel_stride(C: int) -> int:
+    return int(_lib.load().lfgc_grid_channel_stride(int(C)))
+
+
+# ---- wavelet levels ------------------------------------------------------------------------------------
+
+def idwt_level(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, target: Sequence[int],
+               channel_last: bool = False) -> torch.Tensor:
+    """lll (C,d0,d1,d2), hf (C,7,d0,d1,d2) -> (C,t0,t1,t2) or channel-last (t0,t1,t2,Cs)."""
+    _require_hip(lll, hf, filter_rev)
+    lll, hf, filter_rev = _f32c(lll), _f32c(hf), _f32c(filter_rev)
+    C, d0, d1, d2 = lll.shape
+    if tuple(hf.shape) != (C, 7, d0, d1, d2):
+        raise ValueError('detail bands %s do not match low band %s' % (tuple(hf.shape), tuple(lll.shape)))
+    t = [int(v) for v in target]
+    cs = grid_channel_stride(C) if channel_last else C
+    out = torch.empty((t[0], t[1], t[2], cs) if channel_last else (C, t[0], t[1], t[2]),
+                      dtype=torch.float32, device=lll.device)
+    check(_lib.load().lfgc_idwt_level_f32(lll.data_ptr(), hf.data_ptr(), filter_rev.data_ptr(), out.data_ptr(),
+                                          C, d0, d1, d2, t[0], t[1], t[2], int(channel_last), cs, _stream(lll)),
+          'lfgc_idwt_level_f32')
+    return out
+
+
+def idwt_level_bwd(d_out: torch.Tensor, filter_rev: torch.Tensor, C: int, d: Sequence[int], target: Sequence[int],
+                   channel_last: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    _require_hip(d_out, filter_rev)
+    d_out, filter_rev = _f32c(d_out), _f32c(filter_rev)
+    d = [int(v) for v in d]
+    t = [int(v) for v in target]
+    cs = grid_channel_stride(C) if channel_last else C
+    d_lll = torch.empty((C, d[0], d[1], d[2]), dtype=torch.float32, device=d_out.device)
+    d_hf = torch.empty((C, 7, d[0], d[1], d[2]), dtype=torch.float32, device=d_out.device)
+    check(_lib.load().lfgc_idwt_level_bwd_f32(d_out.data_ptr(), filter_rev.data_ptr(), d_lll.data_ptr(), d_hf.data_ptr(),
+                                              C, d[0], d[1], d[2], t[0], t[1], t[2], int(channel_last), cs, _stream(d_out)),
+          'lfgc_idwt_level_bwd_f32')
+    return d_lll, d_hf
+
+
+def dwt_out_shape(n: Sequence[int]) -> List[int]:
+    n = [int(v) for v in n]
+    hi = [2 + (n[2] & 1), 2 + (n[1] & 1), 2 + (n[0] & 1)]     # reference pad-slot quirk, see lfgc.h
+    return [(n[a] + 2 + hi[a] - 4) // 2 + 1 for a in range(3)]
+
+
+def dwt_level(data: torch.Tensor, filter_fwd: torch.Tensor) -> torch.Tensor:
+    """data (C,n0,n1,n2) -> (C,8,d0,d1,d2)."""
+    _require_hip(data, filter_fwd)
+    data, filter_fwd = _f32c(data), _f32c(filter_fwd)
+    C, n0, n1, n2 = data.shape
+    d = dwt_out_shape((n0, n1, n2))
+    out = torch.empty((C, 8, d[0], d[1], d[2]), dtype=torch.float32, device=data.device)
+    check(_lib.load().lfgc_dwt_level_f32(data.data_ptr(), filter_fwd.data_ptr(), out.data_ptr(), C, n0, n1, n2,
+                                         _stream(data)), 'lfgc_dwt_level_f32')
+    return out
+
+
+def decode_levels(coeffs: Sequence[torch.Tensor], shape_array, filter_rev: torch.Tensor,
+                  channel_last: bool) -> torch.Tensor:
+    """All IDWT levels (model/Feature_Grid_Model.py:102-108, drop layers already applied by the caller)."""
+    restored = coeffs[0]
+    n_levels = len(coeffs) - 1
+    if n_levels == 0:
+        raise ValueError('a wavelet-coded grid needs at least one detail level')
+    for i, (hf, shape) in enumerate(zip(coeffs[1:], shape_array)):
+        restored = idwt_level(restored, hf, filter_rev, shape, channel_last=(channel_last and i == n_levels - 1))
+    return restored
+
+
+class DecodeVolumeFn(torch.autograd.Function):
+    """decode_volume() as one autograd node: IDWT chain forward, adjoint chain backward."""
+
+    @staticmethod
+    def forward(ctx, filter_rev, shape_array, channel_last, *coeffs):
+        ctx.filter_rev = filter_rev
+        ctx.shape_array = [tuple(int(v) for v in s) for s in shape_array]
+        ctx.channel_last = bool(channel_last)
+        ctx.dims = [tuple(c.shape) for c in coeffs]
+        with torch.no_grad():
+            return decode_levels([c.detach() for c in coeffs], ctx.shape_array, filter_rev, ctx.channel_last)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        C = ctx.dims[0][0]
+        n_levels = len(ctx.dims) - 1
+        grads = [None] * len(ctx.dims)
+        g = d_out
+        for lvl in range(n_levels, 0, -1):
+            d = ctx.dims[lvl][2:]
+            g, d_hf = idwt_level_bwd(g, ctx.filter_rev, C, d, ctx.shape_array[lvl - 1],
+                                     channel_last=(ctx.channel_last and lvl == n_levels))
+            grads[lvl] = d_hf
+        grads[0] = g
+        return (None, None, None) + tuple(grads)
+
+
+# ---- fused sample + embed + MLP ------------------------------------------------------------------------
+
+def pack_mlp(desc: MlpDesc, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
+    lib = _lib.load()
+    ws = [_f32c(w.detach()) for w in weights]
+    bs = [_f32c(b.detach()) for b in biases]
+    _require_hip(*ws, *bs)
+    nbytes = int(lib.lfgc_packed_bytes(ctypes.byref(desc)))
+    packed = torch.empty(nbytes // 4, dtype=torch.float32, device=ws[0].device)
+    wp, _k1 = _lib.ptr_array([w.data_ptr() for w in ws])
+    bp, _k2 = _lib.ptr_array([b.data_ptr() for b in bs])
+    check(lib.lfgc_pack_mlp_f32(ctypes.byref(desc), wp, bp, packed.data_ptr(), _stream(packed)), 'lfgc_pack_mlp_f32')
+    return packed
+
+
+def _positions_struct(pos: Optional[torch.Tensor], lattice=None) -> Tuple[Positions, int]:
+    ps = Positions()
+    if pos is not None:
+        ps.pos = pos.data_ptr()
+        ps.n = pos.shape[0]
+        ps.res[0] = ps.res[1] = ps.res[2] = 2
+        ps.x_begin, ps.x_end, ps.tile = 0, 0, 32
+        return ps, int(pos.shape[0])
+    res, x_begin, x_end, tile = lattice
+    ps.pos = None
+    ps.n = 0
+    for a in range(3):
+        ps.res[a] = int(res[a])
+    ps.x_begin, ps.x_end, ps.tile = int(x_begin), int(x_end), int(tile)
+    return ps, (int(x_end) - int(x_begin)) * int(res[1]) * int(res[2])
+
+
+def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos: Optional[torch.Tensor] = None,
+                lattice=None, clamp: bool = False, want_stash: bool = False, out: Optional[torch.Tensor] = None):
+    """lfgc_forward_f32.  pos (N,3) or lattice=(res, x_begin, x_end, tile).  Returns (y (N,), stash or None)."""
+    lib = _lib.load()
+    _require_hip(grid_cl, packed, pos)
+    if pos is not None:
+        pos = _f32c(pos)
+    ps, n = _positions_struct(pos, lattice)
+    D, H, W, cs = grid_cl.shape
+    if cs != grid_channel_stride(desc.grid_channels):
+        raise ValueError('channel-last grid has stride %d, expected %d' % (cs, grid_channel_stride(desc.grid_channels)))
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=grid_cl.device)
+    if n == 0:
+        return out, (torch.empty(0, dtype=torch.float32, device=grid_cl.device) if want_stash else None)
+    stash = None
+    if want_stash:
+        stash = torch.empty(int(lib.lfgc_stash_bytes(ctypes.byref(desc), n)) // 4, dtype=torch.float32, device=grid_cl.device)
+    check(lib.lfgc_forward_f32(ctypes.byref(desc), ctypes.byref(ps), grid_cl.data_ptr(), D, H, W, packed.data_ptr(),
+                               int(clamp), out.data_ptr(), stash.data_ptr() if stash is not None else None,
+                               _stream(grid_cl)), 'lfgc_forward_f32')
+    return out, stash
+
+
+def backward_raw(desc: MlpDesc, grid_cl, packed, pos, stash, d_out, weights, biases, need_d_pos: bool):
+    lib = _lib.load()
+    pos = _f32c(pos)
+    d_out = _f32c(d_out)
+    ps, n = _positions_struct(pos)
+    D, H, W, cs = grid_cl.shape
+    dev = grid_cl.device
+    d_grid = torch.zeros_like(grid_cl)
+    d_w = [torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format) for w in weights]
+    d_b = [torch.empty_like(b, dtype=torch.float32, memory_format=torch.contiguous_format) for b in biases]
+    d_pos = torch.empty((n, 3), dtype=torch.float32, device=dev) if need_d_pos else None
+    ws_bytes = int(lib.lfgc_backward_workspace_bytes(ctypes.byref(desc), n))
+    ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev)
+    wp, _k1 = _lib.ptr_array([w.data_ptr() for w in d_w])
+    bp, _k2 = _lib.ptr_array([b.data_ptr() for b in d_b])
+    check(lib.lfgc_backward_f32(ctypes.byref(desc), ctypes.byref(ps), grid_cl.data_ptr(), D, H, W, packed.data_ptr(),
+                                stash.data_ptr(), d_out.data_ptr(), d_grid.data_ptr(), wp, bp,
+                                d_pos.data_ptr() if d_pos is not None else None, ws.data_ptr(), ws_bytes,
+                                _stream(grid_cl)), 'lfgc_backward_f32')
+    return d_grid, d_w, d_b, d_pos
+
+
+class SampleDecodeFn(torch.autograd.Function):
+    """model/Feature_Grid_Model.py:62-75 as one autograd node (HIP forward + HIP backward)."""
+
+    @staticmethod
+    def forward(ctx, desc, pos, grid_cl, packed, n_layers, *params):
+        weights, biases = params[:n_layers + 1], params[n_layers + 1:]
+        need_grad = any(t.requires_grad for t in (pos, grid_cl) + tuple(params))
+        y, stash = forward_raw(desc, grid_cl.detach(), packed, pos=pos.detach(), clamp=False, want_stash=need_grad)
+        if need_grad:
+            ctx.desc = desc
+            ctx.n_layers = n_layers
+            ctx.need_d_pos = pos.requires_grad
+            ctx.save_for_backward(pos.detach(), grid_cl.detach(), packed, stash, *[p.detach() for p in params])
+        return y.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, d_y):
+        pos, grid_cl, packed, stash = ctx.saved_tensors[:4]
+        params = ctx.saved_tensors[4:]
+        L = ctx.n_layers
+        weights, biases = params[:L + 1], params[L + 1:]
+        d_grid, d_w, d_b, d_pos = backward_raw(ctx.desc, grid_cl, packed, pos, stash, d_y.reshape(-1), weights, biases,
+                                               ctx.need_d_pos)
+        return (None, d_pos, d_grid, None, None) + tuple(d_w) + tuple(d_b)
+
+
+# ---- ground truth / statistics -------------------------------------------------------------------------
+
+def gt_interp(p: torch.Tensor, f: torch.Tensor, min_bb, max_bb, res) -> torch.Tensor:
+    lib = _lib.load()
+    _require_hip(p, f)
+    p, f = _f32c(p), _f32c(f)
+    arr = lambda v: (ctypes.c_float * 3)(*[float(x) for x in (v.tolist() if hasattr(v, 'tolist') else v)])
+    out = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+    X, Y, Z = f.shape
+    check(lib.lfgc_gt_interp_f32(p.data_ptr(), f.data_ptr(), arr(min_bb), arr(max_bb), arr(res), p.shape[0], X, Y, Z,
+                                 out.data_ptr(), _stream(p)), 'lfgc_gt_interp_f32')
+    return out
+
+
+def deviation_partial(pred: torch.Tensor, gt: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """acc = [sum sq, sum abs, min gt, max gt] (fp64, device)."""
+    lib = _lib.load()
+    _require_hip(pred, gt)
+    pred, gt = _f32c(pred).reshape(-1), _f32c(gt).reshape(-1)
+    if acc is None:
+        acc = torch.tensor([0.0, 0.0, float('inf'), float('-inf')], dtype=torch.float64, device=pred.device)
+    check(lib.lfgc_deviation_partial_f32(pred.data_ptr(), gt.data_ptr(), pred.numel(), acc.data_ptr(), _stream(pred)),
+          'lfgc_deviation_partial_f32')
+    return acc

@@ -1,0 +1,157 @@
+"""Full-volume reconstruction drivers: counterpart of visualization/OutputToVTK.py
+(field_from_net :7-47, calculate_deviation_statistics :53-60, tiled_net_out :64-82).
+
+* ``field_from_net`` keeps the reference's tile loop and call contract (one ``net(tile)`` per 32^3
+  tile) so existing callers work unchanged.
+* ``field_from_net_fused`` evaluates an x-slab of the volume in ONE kernel launch: the per-tile lattice
+  (same fp32 operation order as the reference's host code) is generated inside the HIP kernel, so no
+  positions are uploaded and nothing is copied back per tile.
+* ``reconstruct_volume_sharded`` cuts the tile lattice into contiguous x-slabs, one per rank
+  (torch.distributed, one process per GPU), and assembles the volume with ONE all-gather (RCCL over xGMI
+  on MI355X; gloo in the CPU tests).  Tiles are independent, the decoded grid is replicated: there is no
+  other communication.
+VTK file output (pyevtk) is out of scope.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import ops
+
+
+def field_from_net(dataset, net, is_cuda, tiled_res=32, verbose=False):
+    """Reference-compatible tile loop (visualization/OutputToVTK.py:7-47)."""
+    target_res = dataset.vol_res_touple
+    full_vol = torch.zeros(target_res)
+    for xdx in np.arange(0, target_res[0], tiled_res):
+        x_begin, x_end = int(xdx), int(min(xdx + tiled_res, target_res[0]))
+        for ydx in np.arange(0, target_res[1], tiled_res):
+            y_begin, y_end = int(ydx), int(min(ydx + tiled_res, target_res[1]))
+            for zdx in np.arange(0, target_res[2], tiled_res):
+                z_begin, z_end = int(zdx), int(min(zdx + tiled_res, target_res[2]))
+                tile_resolution = torch.tensor([x_end - x_begin, y_end - y_begin, z_end - z_begin], dtype=torch.int)
+                min_alpha_bb = torch.tensor([x_begin / (target_res[0] - 1), y_begin / (target_res[1] - 1),
+                                             z_begin / (target_res[2] - 1)], dtype=torch.float)
+                max_alpha_bb = torch.tensor([(x_end - 1) / (target_res[0] - 1), (y_end - 1) / (target_res[1] - 1),
+                                             (z_end - 1) / (target_res[2] - 1)], dtype=torch.float)
+                min_bounds = dataset.min_idx + min_alpha_bb * (dataset.max_idx - dataset.min_idx)
+                max_bounds = dataset.min_idx + max_alpha_bb * (dataset.max_idx - dataset.min_idx)
+                with torch.no_grad():
+                    start = min_bounds / (dataset.max_idx - dataset.min_idx)
+                    end = max_bounds / (dataset.max_idx - dataset.min_idx)
+                    norm_indices = 2.0 * dataset.generate_indices(start, end, tile_resolution) - 1.0
+                    tile_positions = dataset.scales.view(1, 1, 1, 3) * norm_indices
+                    if is_cuda:
+                        tile_positions = tile_positions.unsqueeze(0).cuda()
+                    tile_vol = net(tile_positions.unsqueeze(0)).squeeze(0).squeeze(-1)
+                    full_vol[x_begin:x_end, y_begin:y_end, z_begin:z_end] = tile_vol.cpu()
+    return full_vol
+
+
+def field_from_net_fused(dataset, net, x_begin: int = 0, x_end: Optional[int] = None, tiled_res: int = 32,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Eval-mode forward of ``net`` (a Feature_Grid_Model on the GPU) over the x-slab [x_begin, x_end) of the
+    volume lattice, one launch, result (x_end - x_begin, Y, Z) on the device, clamped like the eval branch."""
+    res = dataset.vol_res_touple
+    x_end = res[0] if x_end is None else int(x_end)
+    with torch.no_grad():
+        grid_cl = net._decoded_channel_last()
+        flat = None if out is None else out.view(-1)
+        y, _ = ops.forward_raw(net._descriptor(), grid_cl, net._packed(), pos=None,
+                               lattice=(res, x_begin, x_end, tiled_res), clamp=True, out=flat)
+    return y.view(x_end - x_begin, res[1], res[2])
+
+
+def calculate_deviation_statistics(prediction, ground_truth, verbose: bool = True):
+    """PSNR / L1 / MSE / RMSE as the reference defines them (:53-60).  GPU tensors are reduced by the HIP
+    kernel with fp64 accumulators; CPU tensors (e.g. the reference-style tile loop's output) by torch."""
+    if prediction.is_cuda and ground_truth.is_cuda:
+        acc = ops.deviation_partial(prediction, ground_truth).cpu()
+        n = prediction.numel()
+        mse = acc[0].item() / n
+        l1 = acc[1].item() / n
+        sqd = (acc[3].item() - acc[2].item()) ** 2
+        psnr = 10.0 * float(np.log10(sqd / mse))
+        rmse = float(np.sqrt(mse))
+    else:
+        diff_vol = ground_truth - prediction
+        sqd_max_diff = (torch.max(ground_truth) - torch.min(ground_truth)) ** 2
+        l1 = torch.mean(torch.abs(diff_vol)).item()
+        mse_t = torch.mean(torch.pow(diff_vol, 2.0))
+        psnr = (10 * torch.log10(sqd_max_diff / mse_t)).item()
+        mse, rmse = mse_t.item(), torch.sqrt(mse_t).item()
+    if verbose:
+        print('PSNR:', psnr, 'l1:', l1, 'mse:', mse, 'rmse:', rmse)
+    return psnr, l1, mse, rmse
+
+
+def tiled_net_out(dataset, net, is_cuda, gt_vol=None, evaluate=True, write_vols=False, filename='vol', fused=True):
+    """Counterpart of tiled_net_out (:64-82): eval(), reconstruct, statistics, back to train()."""
+    if write_vols:
+        raise NotImplementedError('VTK output (pyevtk) is outside the scope of this package')
+    if is_cuda:
+        net = net.cuda()
+    net.eval()
+    if fused and is_cuda:
+        full_vol = field_from_net_fused(dataset, net)
+        if gt_vol is not None:
+            gt_vol = gt_vol.to(full_vol.device)
+    else:
+        full_vol = field_from_net(dataset, net, is_cuda, tiled_res=32)
+    psnr = l1_diff = mse = rmse = 0
+    if evaluate and gt_vol is not None:
+        psnr, l1_diff, mse, rmse = calculate_deviation_statistics(full_vol, gt_vol)
+    net.train()
+    return psnr, l1_diff, mse, rmse
+
+
+# ---- multi-GPU: x-slabs of tiles, one all-gather ---------------------------------------------------------
+
+def slab_partition(res_x: int, world_size: int, tiled_res: int = 32) -> List[Tuple[int, int]]:
+    """Contiguous x ranges [begin, end) per rank, cut on tile boundaries, balanced to within one tile."""
+    n_tiles = (res_x + tiled_res - 1) // tiled_res
+    bounds = []
+    for r in range(world_size):
+        t0 = (r * n_tiles) // world_size
+        t1 = ((r + 1) * n_tiles) // world_size
+        bounds.append((min(t0 * tiled_res, res_x), min(t1 * tiled_res, res_x)))
+    return bounds
+
+
+def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=None,
+                               slab_fn: Optional[Callable[[int, int, torch.Tensor], None]] = None,
+                               device: Optional[torch.device] = None) -> torch.Tensor:
+    """Every rank evaluates its x-slab into a padded (max_slab_x, Y, Z) buffer, ONE all_gather_into_tensor
+    assembles (world, max_slab_x, Y, Z), the padding is trimmed.  Returns the full (X,Y,Z) volume on every rank.
+
+    ``slab_fn(x_begin, x_end, out_view)`` fills ``out_view`` ((x_end-x_begin, Y, Z)); default = the fused HIP
+    forward of ``net``.  (The CPU/gloo tests inject a stub here: the HIP path itself has no CPU form.)"""
+    res = dataset.vol_res_touple
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    parts = slab_partition(res[0], world, tiled_res)
+    max_x = max(e - b for b, e in parts)
+    if device is None:
+        device = next(net.parameters()).device if net is not None else torch.device('cpu')
+    if slab_fn is None:
+        def slab_fn(b, e, out_view):
+            field_from_net_fused(dataset, net, b, e, tiled_res, out=out_view)
+    gathered = torch.empty((world, max_x, res[1], res[2]), dtype=torch.float32, device=device)
+    b, e = parts[rank]
+    if world == 1:
+        if e > b:
+            slab_fn(b, e, gathered[0, :e - b])
+        return gathered[0, :res[0]]
+    mine = torch.zeros((max_x, res[1], res[2]), dtype=torch.float32, device=device)
+    if e > b:
+        slab_fn(b, e, mine[:e - b])
+    dist.all_gather_into_tensor(gathered, mine, group=group)
+    if all(e_ - b_ == max_x for b_, e_ in parts):
+        return gathered.view(world * max_x, res[1], res[2])[:res[0]]
+    return torch.cat([gathered[r, :e_ - b_] for r, (b_, e_) in enumerate(parts)], 0)

@@ -1,0 +1,315 @@
+"""GPU parity tests (through the C-ABI) for the forward side of the hot path: wavelet decode/encode,
+fused sample+embed+MLP forward, ground-truth sampler, full-volume drivers.
+
+Checked against (a) the fixtures captured from the reference's own modules (tests/golden) and (b) the
+oracle (oracle/ref_torch.py on CPU, oracle/ref_explicit.py in fp64) on seeded synthetic models of the
+BASELINE shapes.  Tolerance for the network output (north_star): <= 1e-5 relative fp32, i.e.
+max|y - y_ref| / max|y_ref| <= 1e-5 and allclose(rtol=1e-5, atol=1e-6 * max|y_ref|) with a small
+multiple for the deepest nets, stated per test."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+from oracle import ref_explicit as E
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def rel_err(y, ref):
+    y = np.asarray(y, np.float64).reshape(-1)
+    ref = np.asarray(ref, np.float64).reshape(-1)
+    return np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def build_from_golden(g, dev):
+    from latent_feature_grid_compression_amd.model.Feature_Grid_Model import Feature_Grid_Model
+    from latent_feature_grid_compression_amd.model.Feature_Embedding import FourierEmbedding
+    from latent_feature_grid_compression_amd.wavelet_transform.Torch_Wavelet_Transform import WaveletFilter3d
+    C, G, H, L, nf = [int(v) for v in g['meta']]
+    m = Feature_Grid_Model(FourierEmbedding(nf, 3), torch.zeros(C, G, G, G), None, WaveletFilter3d('db2'),
+                           hidden_channel=H, num_layer=L)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd.')}
+    m.load_state_dict(sd)
+    assert np.array_equal(m.shape_array, g['shape_array'])
+    return m.to(dev)
+
+
+def build_synth(C, G, H, L, seed, dev, num_levels=None):
+    from latent_feature_grid_compression_amd.model.Feature_Grid_Model import Feature_Grid_Model
+    from latent_feature_grid_compression_amd.model.Feature_Embedding import FourierEmbedding
+    from latent_feature_grid_compression_amd.wavelet_transform.Torch_Wavelet_Transform import WaveletFilter3d
+    sm = R.synth_model(C, G, H, L, seed=seed, num_levels=num_levels)
+    m = Feature_Grid_Model(FourierEmbedding(2, 3), torch.zeros(C, G, G, G), None, WaveletFilter3d('db2'),
+                           hidden_channel=H, num_layer=L, num_levels=num_levels)
+    assert np.array_equal(m.shape_array, sm['shape_array'])
+    with torch.no_grad():
+        for p, c in zip(m.feature_grid, sm['coeffs']):
+            p.copy_(c)
+        for lin, w, b in zip(list(m.net_layers) + [m.final_layer], sm['weights'], sm['biases']):
+            lin.weight.copy_(w)
+            lin.bias.copy_(b)
+    return m.to(dev), sm
+
+
+def test_library_loads_and_reports_version(dev):
+    from latent_feature_grid_compression_amd import _lib
+    lib = _lib.load()
+    assert lib.lfgc_version() == 100
+    assert lib.lfgc_error_string(-3).decode().startswith('network shape')
+
+
+def test_device_trig_accuracy(dev):
+    from latent_feature_grid_compression_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.uniform(-40, 40, 400000), np.linspace(-1.6, 1.6, 100001), rng.uniform(-3e4, 3e4, 100000),
+                         np.asarray([0.0, -0.0, 1e-30, 3.14159274, 1.57079637, 32768.0, -32768.0])]).astype(np.float32)
+    x = torch.from_numpy(xs).to(dev)
+    s, c, k = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    rc = lib.lfgc_debug_trig_f32(x.data_ptr(), x.numel(), s.data_ptr(), c.data_ptr(), k.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    x64 = xs.astype(np.float64)
+    assert np.abs(s.cpu().numpy() - np.sin(x64)).max() < 2.5e-7
+    assert np.abs(c.cpu().numpy() - np.cos(x64)).max() < 2.5e-7
+    snake = 0.5 * x64 + np.sin(x64) ** 2
+    assert (np.abs(k.cpu().numpy() - snake) / np.maximum(1.0, np.abs(snake))).max() < 4e-7
+    # wide path: huge / non-finite arguments behave like libm (finite in [-1,1]; nan for inf/nan)
+    big = torch.tensor([1e6, -3.3e7, 1e9, float('inf'), float('nan'), 5e4], dtype=torch.float32, device=dev)
+    s, c, k = torch.empty_like(big), torch.empty_like(big), torch.empty_like(big)
+    assert lib.lfgc_debug_trig_f32(big.data_ptr(), big.numel(), s.data_ptr(), c.data_ptr(), k.data_ptr(), None) == 0
+    sb = s.cpu().numpy()
+    b64 = big.cpu().numpy().astype(np.float64)
+    assert np.abs(sb[[0, 1, 2, 5]] - np.sin(b64[[0, 1, 2, 5]])).max() < 3e-7
+    assert np.isnan(sb[3]) and np.isnan(sb[4])
+
+
+@pytest.mark.parametrize('G', [15, 16, 17])
+def test_wavelet_levels_match_reference(dev, G):
+    from latent_feature_grid_compression_amd import ops
+    g = np.load(os.path.join(GOLD, 'dwt_roundtrip_%d.npz' % G))
+    fl = np.load(os.path.join(GOLD, 'db2_filters.npz'))
+    ffwd, frev = torch.from_numpy(fl['filter_fwd']).to(dev), torch.from_numpy(fl['filter_rev']).to(dev)
+    coeffs = [torch.from_numpy(g['coeff%d' % i]).to(dev) for i in range(len(g['shape_array']) + 1)]
+    dec = ops.decode_levels(coeffs, g['shape_array'], frev, channel_last=False)
+    assert dec.shape == g['decoded'].shape
+    assert np.abs(dec.cpu().numpy() - g['decoded']).max() < 2e-6
+    dec_cl = ops.decode_levels(coeffs, g['shape_array'], frev, channel_last=True)
+    C = g['input'].shape[0]
+    assert dec_cl.shape[-1] == 8 and torch.equal(dec_cl[..., :C].permute(3, 0, 1, 2), dec)
+    assert float(dec_cl[..., C:].abs().max()) == 0.0
+    # forward DWT (init path), level by level like encode_volume
+    data = torch.from_numpy(g['input']).to(dev)
+    for lvl in range(len(g['shape_array']), 0, -1):
+        out = ops.dwt_level(data, ffwd)
+        assert np.abs(out[:, 1:].cpu().numpy() - g['coeff%d' % lvl]).max() < 2e-6
+        data = out[:, 0].contiguous()
+    assert np.abs(data.cpu().numpy() - g['coeff0']).max() < 2e-6
+
+
+def test_wavelet_noncubic_and_adjoint(dev):
+    from latent_feature_grid_compression_amd import ops
+    g = np.load(os.path.join(GOLD, 'dwt_noncubic.npz'))
+    fl = np.load(os.path.join(GOLD, 'db2_filters.npz'))
+    ffwd, frev = torch.from_numpy(fl['filter_fwd']).to(dev), torch.from_numpy(fl['filter_rev']).to(dev)
+    out = ops.dwt_level(torch.from_numpy(g['input'][0]).to(dev), ffwd)
+    assert np.abs(out.cpu().numpy() - g['coeffs'][0]).max() < 2e-6
+    co = torch.from_numpy(g['coeffs'][0]).to(dev)
+    dec = ops.idwt_level(co[:, 0].contiguous(), co[:, 1:].contiguous(), frev, g['shape'])
+    assert np.abs(dec.cpu().numpy() - g['decoded'][0]).max() < 2e-6
+    # adjoint vs autograd of the oracle's conv_transpose3d + crop, both layouts
+    rng = np.random.default_rng(5)
+    d_out = torch.from_numpy(rng.standard_normal(g['decoded'][0].shape).astype(np.float32))
+    data = torch.from_numpy(g['coeffs']).clone().requires_grad_(True)
+    ref = R.wavelet_decode(data, g['shape'], torch.from_numpy(fl['filter_rev']))
+    ref.backward(d_out.unsqueeze(0))
+    d = g['coeffs'].shape[-3:]
+    for cl in (False, True):
+        if cl:
+            dd = torch.zeros(*d_out.shape[1:], 8)
+            dd[..., :2] = d_out.permute(1, 2, 3, 0)
+        else:
+            dd = d_out
+        d_lll, d_hf = ops.idwt_level_bwd(dd.to(dev), frev, 2, d, g['shape'], channel_last=cl)
+        assert np.abs(d_lll.cpu().numpy() - data.grad[0, :, 0].numpy()).max() < 5e-6
+        assert np.abs(d_hf.cpu().numpy() - data.grad[0, :, 1:].numpy()).max() < 5e-6
+
+
+FWD = ['fwd_cfg1_c16g16h32l2.npz', 'fwd_c4g15h16l3.npz', 'fwd_c6g17h32l4.npz', 'fwd_c2g32h64l4.npz']
+
+
+@pytest.mark.parametrize('name', FWD)
+def test_forward_matches_reference_fixture(dev, name):
+    g = np.load(os.path.join(GOLD, name))
+    m = build_from_golden(g, dev)
+    m.train()
+    with torch.no_grad():
+        dec = m.decode_volume()
+        assert np.abs(dec.cpu().numpy() - g['decoded']).max() < 3e-6
+        y = m(torch.from_numpy(g['pos']).to(dev))
+    assert y.shape == (g['pos'].shape[0], 1)
+    yr = g['y']
+    assert rel_err(y.cpu().numpy(), yr) <= 1e-5
+    assert np.allclose(y.cpu().numpy(), yr, rtol=1e-5, atol=2e-6 * np.abs(yr).max())
+    # eval branch: tile-shaped input, clamped, same leading dims
+    m.eval()
+    with torch.no_grad():
+        yev = m(torch.from_numpy(g['eval_pos']).to(dev))
+    assert yev.shape == (1, 1, 8, 9, 10, 1)
+    assert rel_err(yev.cpu().numpy(), g['eval_y']) <= 1e-5
+    assert float(yev.max()) <= 1.0 and float(yev.min()) >= -1.0
+
+
+def _decode_stash(stash, n, KS0, L, MT):
+    """Private stash layout -> x0 in packed k order (N, 2*KS0) and pre-activations (L, N, 32*MT)."""
+    per_tile = 64 * (KS0 + L * 16 * MT)
+    tiles = stash.numel() // per_tile
+    st = stash.view(tiles, KS0 + L * 16 * MT, 64).cpu().numpy()
+    x0 = np.zeros((tiles * 32, 2 * KS0), np.float32)
+    pre = np.zeros((L, tiles * 32, 32 * MT), np.float32)
+    for lane in range(64):
+        j, hh = lane & 31, lane >> 5
+        for s in range(KS0):
+            x0[j::32, 8 * (s // 4) + 4 * hh + (s % 4)] = st[:, s, lane]
+        for l in range(L):
+            for mr in range(16 * MT):
+                m_, r = mr // 16, mr % 16
+                row = 32 * m_ + (r & 3) + 8 * (r >> 2) + 4 * hh
+                pre[l, j::32, row] = st[:, KS0 + l * 16 * MT + mr, lane]
+    return x0[:n], pre[:, :n]
+
+
+def test_stash_holds_reference_preactivations(dev):
+    """The values saved for backward are the reference's layer-0 input and pre-activations."""
+    from latent_feature_grid_compression_amd import ops
+    g = np.load(os.path.join(GOLD, 'fwd_cfg1_c16g16h32l2.npz'))
+    m = build_from_golden(g, dev)
+    pos = torch.from_numpy(g['pos']).to(dev)
+    with torch.no_grad():
+        grid = m._decoded_channel_last()
+        y, stash = ops.forward_raw(m._descriptor(), grid, m._packed(), pos=pos, want_stash=True)
+    C, G, H, L, nf = [int(v) for v in g['meta']]
+    x0, pre = _decode_stash(stash, pos.shape[0], (16 + 16) // 2, L, 1)
+    # packed column order of layer 0 -> reference column order [p, emb, feat]
+    ref_x0 = g['x0']
+    for cl in range(32):
+        s, hh = (cl >> 3) * 4 + (cl & 3), (cl >> 2) & 1
+        if s < 8:
+            src = 15 + hh * 8 + s
+        else:
+            e = hh * 8 + (s - 8)
+            src = e if e < 15 else None
+        if src is None:
+            assert np.all(x0[:, cl] == 0)
+        else:
+            assert np.abs(x0[:, cl] - ref_x0[:, src]).max() < 2e-6, (cl, src)
+    for l in range(L):
+        assert np.abs(pre[l][:, :H] - g['pre%d' % l]).max() < 1e-5 * max(1.0, np.abs(g['pre%d' % l]).max())
+
+
+@pytest.mark.parametrize('C,G,H,L,n,tol', [
+    (16, 32, 64, 4, 50000, 1e-5),      # BASELINE cfg 2
+    (32, 64, 128, 4, 40000, 1e-5),     # BASELINE cfg 3/4
+    (22, 17, 32, 4, 10001, 1e-5),      # reference experiment configs: odd grid, 22 channels, ragged N
+    (3, 15, 100, 1, 77, 1e-5),         # padding everywhere: C 3->8, H 100->128, one layer, N < one tile
+    (32, 20, 128, 8, 4096, 2e-5),      # deepest supported net
+])
+def test_forward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n, tol):
+    m, sm = build_synth(C, G, H, L, seed=4000 + C + G + H, dev=dev)
+    rng = np.random.default_rng(C * 1000 + G)
+    pos = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32))
+    pos[:8] = torch.tensor([[sx, sy, sz] for sx in (-1., 1.) for sy in (-1., 1.) for sz in (-1., 1.)])[:min(8, n)]
+    m.train()
+    with torch.no_grad():
+        y = m(pos.to(dev)).cpu().numpy()
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    dense = R.decode_volume(sm['coeffs'], sm['shape_array'], sm['filter_rev'])
+    yref = R.forward_from_grid(dense, sm['weights'], sm['biases'], pos, 2).numpy()
+    assert rel_err(y, yref) <= tol
+    # fp64 truth: the HIP path must not be further from it than ~the fp32 CPU path is
+    sub = slice(0, min(n, 4000))
+    y64 = E.forward_from_grid(E.decode_volume([c.numpy() for c in sm['coeffs']], sm['shape_array'], sm['filter_rev'].numpy()),
+                              [w.numpy() for w in sm['weights']], [b.numpy() for b in sm['biases']], pos[sub].numpy(), 2)
+    e_hip, e_cpu = rel_err(y[sub], y64), rel_err(yref[sub], y64)
+    assert e_hip <= max(3 * e_cpu, 3e-6), (e_hip, e_cpu)
+
+
+def test_gt_interpolation_bit_exact(dev):
+    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_f_interpolation
+    g = np.load(os.path.join(GOLD, 'gt_interp.npz'))
+    for tag in ('a', 'b'):
+        vol = torch.from_numpy(g['vol_' + tag])
+        ds = R.VolumeIndexing(vol.shape)
+        for kind in ('lat', 'frac'):
+            p = torch.from_numpy(g[kind + '_' + tag]).to(dev)
+            out = trilinear_f_interpolation(p, vol.to(dev), ds.min_idx, ds.max_idx, ds.vol_res)
+            assert np.array_equal(out.cpu().numpy(), g['gt_%s_%s' % (kind, tag)]), (tag, kind)
+
+
+def test_full_volume_drivers_match_reference_tiles(dev):
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    from latent_feature_grid_compression_amd.visualization import OutputToVTK as V
+    g = np.load(os.path.join(GOLD, 'tiles_70x40x33.npz'))
+    gm = np.load(os.path.join(GOLD, 'fwd_c4g15h16l3.npz'))
+    m = build_from_golden(gm, dev)
+    vol = torch.from_numpy(g['volume'])
+    ds = IndexDataset(vol, 16)
+    m.eval()
+    full_loop = V.field_from_net(ds, m, is_cuda=True, tiled_res=32)          # reference-style: 12 net(tile) calls
+    assert rel_err(full_loop.numpy(), g['full_vol']) <= 1e-5
+    full_fused = V.field_from_net_fused(ds, m)                               # one launch, lattice built in-kernel
+    assert full_fused.shape == vol.shape
+    assert rel_err(full_fused.cpu().numpy(), g['full_vol']) <= 1e-5
+    # slabs: any tile-aligned x range reproduces the same voxels
+    part = V.field_from_net_fused(ds, m, 32, 70)
+    assert torch.equal(part, full_fused[32:70])
+    stats = V.calculate_deviation_statistics(full_fused, vol.to(dev), verbose=False)
+    assert abs(stats[0] - g['stats'][0]) < 1e-3                              # PSNR within 0.01 dB (north_star)
+    assert np.allclose(stats[1:], g['stats'][1:], rtol=2e-5)
+    single = V.reconstruct_volume_sharded(ds, m)                             # world size 1 path
+    assert torch.equal(single, full_fused)
+
+
+def test_eval_cache_tracks_parameter_updates(dev):
+    m, sm = build_synth(8, 16, 32, 2, seed=91, dev=dev)
+    m.eval()
+    pos = torch.rand(1, 4, 4, 4, 3, device=dev) * 2 - 1
+    with torch.no_grad():
+        y1 = m(pos)
+        y1b = m(pos)
+        assert torch.equal(y1, y1b)
+        m.feature_grid[0].mul_(1.5)                  # in-place update must invalidate the decoded-grid cache
+        m.final_layer.bias.add_(0.25)                # ... and the packed-parameter cache
+        y2 = m(pos)
+    assert not torch.equal(y1, y2)
+    coeffs = [p.detach().cpu() for p in m.feature_grid]
+    w = [l.weight.detach().cpu() for l in list(m.net_layers) + [m.final_layer]]
+    b = [l.bias.detach().cpu() for l in list(m.net_layers) + [m.final_layer]]
+    yref = R.forward(coeffs, sm['shape_array'], sm['filter_rev'], w, b, pos.cpu(), 2, training=False)
+    assert rel_err(y2.cpu().numpy(), yref.numpy()) <= 1e-5
+
+
+def test_rejects_cpu_tensors_and_bad_shapes(dev):
+    from latent_feature_grid_compression_amd import _lib, ops
+    m, _ = build_synth(8, 16, 32, 2, seed=92, dev=dev)
+    with pytest.raises(_lib.LfgcError):
+        m(torch.zeros(4, 3))                         # CPU input: no silent fallback
+    with pytest.raises(ValueError):
+        m.train()(torch.zeros(4, 2, device=dev))
+    with pytest.raises(_lib.LfgcError):
+        ops.make_desc(64, 32, 2, 2)                  # outside the compiled kernel set
+    y = m.train()(torch.zeros(0, 3, device=dev))     # empty batch
+    assert y.shape == (0, 1)
