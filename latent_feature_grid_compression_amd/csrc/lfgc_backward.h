@@ -1,0 +1,542 @@
+// lfgc_backward.h -- backward of the fused sample + embed + MLP path for gfx950 (exact fp32 MFMA).
+//
+// What autograd derives for model/Feature_Grid_Model.py:62-75 in the reference (triggered at
+// training/training.py:137), as three kernels:
+//   1. lfgc_bwd_data_kernel   per 32-sample wave tile, the forward's register mapping run backwards:
+//        dH_L = Wf dy ; for l = L..1: dA_l = dH_l * snake'(a_l) (a_l from the forward's stash),
+//        dH_{l-1} = W_l^T dA_l  (A operand = transposed weight image in LDS, B operand = dA_l in VGPRs,
+//        the accumulators are again the next step's B operand), dX0 = W_0^T dA_1 lands in exactly the
+//        registers the forward's layer-0 input occupied: grid-feature gradients -> float-atomic scatter into
+//        the channel-last d_grid (staged through LDS so that one atomic wave-instruction covers whole 128-B
+//        channel rows), scalar-input gradients (+ the sampler's coordinate gradient) -> d_pos.
+//        dA_l is also written to a scratch "dstash" for kernel 2.
+//   2. lfgc_bwd_weight_kernel  dW_l = dA_l^T H_{l-1}: contraction over SAMPLES (K = 32 per tile), M = h_out,
+//        N = k_in; operands are read back from stash/dstash so that 16 consecutive samples of one row are one
+//        64-byte load per lane; each workgroup accumulates its share of the sample tiles in registers and
+//        writes one partial slab.
+//   3. lfgc_bwd_reduce_kernel  sums the slabs into the nn.Linear-shaped gradients (deterministic, no atomics).
+#pragma once
+#include "lfgc_common.h"
+
+struct LfgcBwdArgs {
+    const float* pos;          // (N,3)
+    long long n;
+    const float* grid;         // (D,H,W,Cs)   (read only when d_pos is requested)
+    int D, H, W, Cs;
+    const float* packed;
+    int L;
+    const float* stash;
+    const float* d_out;        // (N)
+    float* dstash;             // [tiles][L*16*MT][64]
+    float* d_grid;             // (D,H,W,Cs), accumulated with float atomics
+    float* d_pos;              // (N,3) or nullptr
+    long long nbatches;
+};
+
+// acc += W_tile . B for one 32-row M tile; `arow` = LDS address of (row 32m + lane&31, column 4*(lane>>5)).
+template <int KS>
+__device__ __forceinline__ f32x16 lfgc_mfma_tile(const float* __restrict__ arow, const float (&Bin)[KS], f32x16 acc) {
+    static_assert(KS % 4 == 0, "k-steps come in groups of 4 (one ds_read_b128)");
+#pragma unroll
+    for (int qb = 0; qb < KS / 4; ++qb) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * qb);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, Bin[4 * qb + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, Bin[4 * qb + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, Bin[4 * qb + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, Bin[4 * qb + 3], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// dA[i] = dH[i] * snake'(a[i]) for the 16*MT pre-activations of one layer (a read from the stash slot).
+template <int MT>
+__device__ __forceinline__ void lfgc_snake_bwd(const float* __restrict__ slot, const float (&dH)[16 * MT],
+                                               float (&dA)[16 * MT], int lane) {
+    float av[16 * MT];
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 16 * MT; ++i) {
+        av[i] = slot[i * 64 + lane];
+        bad |= lfgc_trig_out_of_range(av[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<false>(av[i]);
+    if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+        for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<true>(av[i]);
+    }
+}
+
+template <int CH, int MT, int NF>
+__global__ __launch_bounds__(256, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs a) {
+    constexpr int E = 3 + 6 * NF;
+    constexpr int EP = (E + 7) / 8 * 8;
+    constexpr int K0P = CH + EP;
+    constexpr int K0R = (K0P + 31) / 32 * 32;
+    constexpr int KS0 = K0P / 2;
+    constexpr int HP = 32 * MT;
+    constexpr int KS1 = HP / 2;
+    constexpr int S0 = K0P + 4, S1 = HP + 4, ST = HP + 4;
+    constexpr int BLK0 = HP * S0 + HP, BLK1 = HP * S1 + HP;
+    constexpr int TB0 = K0R * ST, TB1 = HP * ST;
+    constexpr int CHH = CH / 2, EPH = EP / 2;
+    constexpr int TXF = (CHH + 15) / 16;         // M tiles of dX0 that hold grid-feature gradients
+    constexpr int TXA = K0R / 32;                // ... all of dX0 (features + scalar inputs)
+    constexpr int SCS = CH + 4;                  // scatter staging row stride (floats)
+    constexpr int SC_WAVE = 32 * (SCS + 16);     // per wave: dfeat rows + 8 weights + 8 offsets per sample
+    constexpr int SPI = 64 / CH;                 // samples covered by one atomic wave-instruction
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_final = smem;               // Wf (HP) | bf (4)
+    float* s_w = smem + HP + 4;          // transposed weight image of the current layer / scatter staging
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, hh = lane >> 5;
+    const int L = a.L;
+    const int off_final = BLK0 + (L - 1) * BLK1;
+    const int off_t = off_final + HP + 4;
+    const long long per_tile = 64LL * (KS0 + L * 16 * MT);
+    const long long dper_tile = 64LL * (L * 16 * MT);
+
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_final);
+        for (int i = tid; i < (HP + 4) / 4; i += 256) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
+    }
+    __syncthreads();
+
+    const long long N = a.n;
+    for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
+        const long long tile_idx = batch * LFGC_WG_WAVES + wave;
+        const long long n = tile_idx * LFGC_TILE_SAMPLES + j;
+        const bool valid = n < N;
+        const long long nc = valid ? n : (N - 1);
+        const float dy = valid ? a.d_out[n] : 0.0f;
+        const float* st_tile = a.stash + tile_idx * per_tile;
+        float* dst_tile = a.dstash + tile_idx * dper_tile;
+
+        // ---- final Linear backward: dH_L[k] = Wf[k] * dy -------------------------------------------------
+        float dH[16 * MT];
+#pragma unroll
+        for (int qb = 0; qb < KS1 / 4; ++qb) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_final + 8 * qb + 4 * hh);
+            dH[4 * qb + 0] = w4.x * dy; dH[4 * qb + 1] = w4.y * dy;
+            dH[4 * qb + 2] = w4.z * dy; dH[4 * qb + 3] = w4.w * dy;
+        }
+
+        // ---- hidden layers L-1 .. 1 (0-based): dA = dH * snake'(a), dH_prev = W^T dA ------------------------
+        for (int l = L - 1; l >= 1; --l) {
+            float dA[16 * MT];
+            lfgc_snake_bwd<MT>(st_tile + 64 * KS0 + (long long)l * (64 * 16 * MT), dH, dA, lane);
+#pragma unroll
+            for (int i = 0; i < 16 * MT; ++i) dst_tile[(long long)l * (64 * 16 * MT) + i * 64 + lane] = dA[i];
+            __syncthreads();
+            {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_t + TB0 + (long long)(l - 1) * TB1);
+                for (int i = tid; i < TB1 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+            }
+            __syncthreads();
+            const float* s_row = s_w + j * ST + 4 * hh;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dH[16 * m + r] = acc[r];
+            }
+        }
+
+        // ---- layer 0: dA_1, then dX0 = W_0^T dA_1 in the forward's input register layout ------------------------
+        float dX[16 * TXA];
+        {
+            float dA[16 * MT];
+            lfgc_snake_bwd<MT>(st_tile + 64 * KS0, dH, dA, lane);
+#pragma unroll
+            for (int i = 0; i < 16 * MT; ++i) dst_tile[i * 64 + lane] = dA[i];
+            __syncthreads();
+            {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_t);
+                for (int i = tid; i < TB0 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
+            }
+            __syncthreads();
+            const float* s_row = s_w + j * ST + 4 * hh;
+#pragma unroll
+            for (int m = 0; m < TXA; ++m) {
+                if (m < TXF || a.d_pos) {            // scalar-input rows only when d_pos is wanted (wave-uniform)
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dX[16 * m + r] = acc[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dX[16 * m + r] = 0.0f;
+                }
+            }
+        }
+
+        // ---- sampler geometry (same arithmetic as the forward) ---------------------------------------------
+        const float* pp = a.pos + 3 * nc;
+        const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+        const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p0, 1.0f), (float)a.W), 1.0f), 2.0f);
+        const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p1, 1.0f), (float)a.H), 1.0f), 2.0f);
+        const float iz = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p2, 1.0f), (float)a.D), 1.0f), 2.0f);
+        const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+        const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)a.W);
+        const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)a.H);
+        const int z0 = (int)fminf(fmaxf(fz0, -2.0f), (float)a.D);
+        const float wx1 = __fsub_rn(ix, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+        const float wy1 = __fsub_rn(iy, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+        const float wz1 = __fsub_rn(iz, fz0), wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
+        const bool in_range = (fx0 >= -1.0f) && (fx0 < (float)a.W) && (fy0 >= -1.0f) && (fy0 < (float)a.H) &&
+                              (fz0 >= -1.0f) && (fz0 < (float)a.D);
+
+        // ---- scatter d feat into d_grid: stage [sample][channel] + per-corner weight/offset in LDS ----------
+        __syncthreads();                                  // every wave is done with the weight image
+        float* s_df = s_w + wave * SC_WAVE;               // [32][SCS]
+        float* s_cw = s_df + 32 * SCS;                    // [32][8] corner weights
+        int* s_co = reinterpret_cast<int*>(s_cw + 32 * 8);   // [32][8] corner row offsets (floats)
+#pragma unroll
+        for (int c4 = 0; c4 < CHH / 4; ++c4) {
+            f32x4 v;
+            v.x = dX[4 * c4 + 0]; v.y = dX[4 * c4 + 1]; v.z = dX[4 * c4 + 2]; v.w = dX[4 * c4 + 3];
+            *reinterpret_cast<f32x4*>(s_df + j * SCS + hh * CHH + 4 * c4) = v;
+        }
+        float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int dz = corner >> 2, dyc = (corner >> 1) & 1, dx = corner & 1;
+            const int xi = x0 + dx, yi = y0 + dyc, zi = z0 + dz;
+            const bool ok = valid && in_range && xi >= 0 && xi < a.W && yi >= 0 && yi < a.H && zi >= 0 && zi < a.D;
+            const float wxc = dx ? wx1 : wx0, wyc = dyc ? wy1 : wy0, wzc = dz ? wz1 : wz0;
+            const float w = ok ? __fmul_rn(__fmul_rn(wxc, wyc), wzc) : 0.0f;
+            const int xc = min(max(xi, 0), a.W - 1), yc = min(max(yi, 0), a.H - 1), zc = min(max(zi, 0), a.D - 1);
+            const long long off = ((long long)(zc * a.H + yc) * a.W + xc) * a.Cs;
+            if (hh == 0) s_cw[j * 8 + corner] = w; else s_co[j * 8 + corner] = (int)off;
+            if (a.d_pos && ok) {                           // sampler coordinate gradient (ATen grid_sampler_3d_backward)
+                const float* gp = a.grid + off + hh * CHH;
+                float dot = 0.0f;
+#pragma unroll
+                for (int c4 = 0; c4 < CHH / 4; ++c4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(gp + 4 * c4);
+                    dot = __builtin_fmaf(v.x, dX[4 * c4 + 0], dot); dot = __builtin_fmaf(v.y, dX[4 * c4 + 1], dot);
+                    dot = __builtin_fmaf(v.z, dX[4 * c4 + 2], dot); dot = __builtin_fmaf(v.w, dX[4 * c4 + 3], dot);
+                }
+                gix += (dx ? dot : -dot) * (wyc * wzc);
+                giy += (dyc ? dot : -dot) * (wxc * wzc);
+                giz += (dz ? dot : -dot) * (wxc * wyc);
+            }
+        }
+        __syncthreads();                                  // staging visible to every lane that reads it
+        {
+            const int sp = lane / CH, c = lane % CH;
+            if (sp < SPI) {
+                for (int i = 0; i < (32 + SPI - 1) / SPI; ++i) {
+                    const int smp = i * SPI + sp;
+                    if (smp < 32) {
+                        const float v = s_df[smp * SCS + c];
+#pragma unroll
+                        for (int corner = 0; corner < 8; ++corner) {
+                            const float w = s_cw[smp * 8 + corner];
+                            if (w != 0.0f) atomicAdd(a.d_grid + s_co[smp * 8 + corner] + c, v * w);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- d_pos = direct columns + Fourier embedding + sampler coordinate gradient ---------------------------
+        if (a.d_pos) {
+            float sk[NF > 0 ? NF : 1][3], ck[NF > 0 ? NF : 1][3];
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const float f = lfgc_freq(k);
+                const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f);
+                bad |= lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2);
+                lfgc_sincosf_t<false>(a0, sk[k][0], ck[k][0]);
+                lfgc_sincosf_t<false>(a1, sk[k][1], ck[k][1]);
+                lfgc_sincosf_t<false>(a2, sk[k][2], ck[k][2]);
+            }
+            if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    const float f = lfgc_freq(k);
+                    lfgc_sincosf_t<true>(__fmul_rn(p0, f), sk[k][0], ck[k][0]);
+                    lfgc_sincosf_t<true>(__fmul_rn(p1, f), sk[k][1], ck[k][1]);
+                    lfgc_sincosf_t<true>(__fmul_rn(p2, f), sk[k][2], ck[k][2]);
+                }
+            }
+            // this lane holds d e[hh*EPH + t] in dX[CHH + t]; evaluate both static mappings, keep this half's
+            float dlo[3] = {0.0f, 0.0f, 0.0f}, dhi[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < EPH; ++t) {
+                const float d = dX[CHH + t];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int e = half * EPH + t;
+                    float* acc3 = half ? dhi : dlo;
+                    if (e < 3) {
+                        acc3[e] += d;
+                    } else if (e < E) {
+                        const int k = (e - 3) / 6, wch = (e - 3) % 6;
+                        const float f = lfgc_freq(k);
+                        if (wch < 3) acc3[wch] += d * f * ck[k][wch];
+                        else acc3[wch - 3] -= d * f * sk[k][wch - 3];
+                    }
+                }
+            }
+            float g0 = (hh ? dhi[0] : dlo[0]) + gix * (0.5f * (float)a.W);
+            float g1 = (hh ? dhi[1] : dlo[1]) + giy * (0.5f * (float)a.H);
+            float g2 = (hh ? dhi[2] : dlo[2]) + giz * (0.5f * (float)a.D);
+            g0 += __shfl_xor(g0, 32); g1 += __shfl_xor(g1, 32); g2 += __shfl_xor(g2, 32);
+            if (valid && hh == 0) {
+                a.d_pos[3 * n + 0] = g0; a.d_pos[3 * n + 1] = g1; a.d_pos[3 * n + 2] = g2;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradients
+// ---------------------------------------------------------------------------------------------------------
+struct LfgcWgradArgs {
+    const float* stash;
+    const float* dstash;
+    const float* d_out;
+    long long n;
+    long long ntiles;          // 32-sample tiles that hold data (multiple of 4: whole workgroup batches)
+    int L;
+    float* slabs;              // [gridDim.x][slab_floats]
+    int slab_floats;
+};
+
+// Slab layout (floats): per hidden layer l: dW [HP][NC_l] (NC_0 = K0R in packed column order, else HP) | db [HP];
+// then final layer: dWf [HP] | dbf [4].
+__host__ __device__ inline int lfgc_slab_layer_off(const LfgcPlan& p, int l) {
+    return l == 0 ? 0 : (p.HP * p.K0R + p.HP) + (l - 1) * (p.HP * p.HP + p.HP);
+}
+__host__ __device__ inline int lfgc_slab_floats(const LfgcPlan& p) { return lfgc_slab_layer_off(p, p.L) + p.HP + 4; }
+
+// 16 consecutive samples (16*kk .. 16*kk+15) of stash row `row16` (= (m*16 + r)*64 + hh*32) -> v[16]
+__device__ __forceinline__ void lfgc_load16(const float* __restrict__ base, float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(base + 4 * q);
+        v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
+// One layer's dW (+ db) over this workgroup's sample tiles.  NT = column tiles of this layer, KSIN = stash
+// registers of the input (KS0 for layer 0 where the input is the saved x0, else 16*MT pre-activations).
+template <int MT, int NT, bool LAYER0, int KS0>
+__device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, float* __restrict__ slab_l, int ncol,
+                                                 int k0p, long long per_tile, long long dper_tile,
+                                                 int lane, int wave) {
+    constexpr int WPN = 4 / NT;                       // waves sharing one column tile
+    constexpr int TPW = (MT + WPN - 1) / WPN;         // row tiles per wave
+    const int n_t = wave % NT, msub = wave / NT;
+    const int i = lane & 31, kk = lane >> 5;
+    f32x16 acc[TPW];
+    float dbp[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        dbp[t] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    }
+    // B operand row for this lane: column col = 32 n_t + i of the layer input
+    const int col = 32 * n_t + i;
+    long long boff;
+    bool bvalid = true;
+    if (LAYER0) {
+        const int s = 4 * (col >> 3) + (col & 3), hb = (col >> 2) & 1;
+        bvalid = col < k0p;
+        boff = (long long)(bvalid ? s : 0) * 64 + hb * 32 + 16 * kk;
+    } else {
+        const int r = (i & 3) + 4 * (i >> 3), hb = (i >> 2) & 1;
+        boff = 64LL * KS0 + (long long)(l - 1) * (64 * 16 * MT) + (long long)(n_t * 16 + r) * 64 + hb * 32 + 16 * kk;
+    }
+    // A operand rows: row = 32 m + i of dA_l
+    const int ra = (i & 3) + 4 * (i >> 3), ha = (i >> 2) & 1;
+    const long long aoff_base = (long long)l * (64 * 16 * MT) + (long long)ra * 64 + ha * 32 + 16 * kk;
+
+    for (long long t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        float Bv[16];
+        lfgc_load16(a.stash + t * per_tile + boff, Bv);
+        if (LAYER0) {
+            if (!bvalid) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Bv[s] = 0.0f;
+            }
+        } else {
+            bool bad = false;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bad |= lfgc_trig_out_of_range(Bv[s]);
+            float Hv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<false>(Bv[s]);
+            if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<true>(Bv[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) Bv[s] = Hv[s];
+        }
+#pragma unroll
+        for (int tw = 0; tw < TPW; ++tw) {
+            const int m = msub + tw * WPN;
+            if (m < MT) {
+                float Av[16];
+                lfgc_load16(a.dstash + t * dper_tile + aoff_base + (long long)m * (16 * 64), Av);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    acc[tw] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[s], Bv[s], acc[tw], 0, 0, 0);
+                    dbp[tw] += Av[s];
+                }
+            }
+        }
+    }
+    // write this workgroup's partial: dW[32m + row][32 n_t + colj], rows from the accumulator layout
+    const int cj = lane & 31, hc = lane >> 5;
+#pragma unroll
+    for (int tw = 0; tw < TPW; ++tw) {
+        const int m = msub + tw * WPN;
+        if (m < MT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hc;
+                slab_l[(long long)row * ncol + 32 * n_t + cj] = acc[tw][r];
+            }
+            const float tot = dbp[tw] + __shfl_xor(dbp[tw], 32);
+            if (n_t == 0 && kk == 0) slab_l[(long long)(32 * MT) * ncol + 32 * m + i] = tot;
+        }
+    }
+}
+
+template <int CH, int MT, int NF>
+__global__ __launch_bounds__(256, 2) void lfgc_bwd_weight_kernel(const LfgcWgradArgs a) {
+    constexpr int E = 3 + 6 * NF;
+    constexpr int EP = (E + 7) / 8 * 8;
+    constexpr int K0P = CH + EP;
+    constexpr int K0R = (K0P + 31) / 32 * 32;
+    constexpr int KS0 = K0P / 2;
+    constexpr int HP = 32 * MT;
+    constexpr int NT0 = K0R / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = a.L;
+    const long long per_tile = 64LL * (KS0 + L * 16 * MT);
+    const long long dper_tile = 64LL * (L * 16 * MT);
+    float* slab = a.slabs + (long long)blockIdx.x * a.slab_floats;
+
+    lfgc_wgrad_layer<MT, NT0, true, KS0>(a, 0, slab, K0R, K0P, per_tile, dper_tile, lane, wave);
+    for (int l = 1; l < L; ++l) {
+        float* slab_l = slab + (HP * K0R + HP) + (long long)(l - 1) * (HP * HP + HP);
+        lfgc_wgrad_layer<MT, MT, false, KS0>(a, l, slab_l, HP, K0P, per_tile, dper_tile, lane, wave);
+    }
+
+    // final Linear: dWf[k] = sum_n dy_n H_L[n,k], dbf = sum_n dy_n.  Wave w owns column tile w.
+    {
+        float* slab_f = slab + (HP * K0R + HP) + (long long)(L - 1) * (HP * HP + HP);
+        const int i = lane & 31, kk = lane >> 5;
+        float wsum = 0.0f, bsum = 0.0f;
+        if (wave < MT) {
+            const int r = (i & 3) + 4 * (i >> 3), hb = (i >> 2) & 1;
+            const long long boff = 64LL * KS0 + (long long)(L - 1) * (64 * 16 * MT) + (long long)(wave * 16 + r) * 64 + hb * 32 + 16 * kk;
+            for (long long t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+                float Bv[16];
+                lfgc_load16(a.stash + t * per_tile + boff, Bv);
+                bool bad = false;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bad |= lfgc_trig_out_of_range(Bv[s]);
+                float Hv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<false>(Bv[s]);
+                if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<true>(Bv[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const long long smp = t * 32 + 16 * kk + s;
+                    const float dyv = smp < a.n ? a.d_out[smp] : 0.0f;
+                    wsum = __builtin_fmaf(dyv, Hv[s], wsum);
+                    bsum += dyv;
+                }
+            }
+            wsum += __shfl_xor(wsum, 32);
+            bsum += __shfl_xor(bsum, 32);
+            if (kk == 0) slab_f[32 * wave + i] = wsum;
+            if (wave == 0 && lane == 0) slab_f[HP] = bsum;
+        }
+    }
+}
+
+struct LfgcReduceArgs {
+    const float* slabs;
+    int nslabs, slab_floats;
+    float* dw[LFGC_MAX_LAYERS + 1];
+    float* db[LFGC_MAX_LAYERS + 1];
+    LfgcPlan plan;
+    int col_of_src[64];        // layer 0: packed column that holds original column c
+};
+
+// d_weights / d_biases in nn.Linear layout = sum over workgroup slabs.
+static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcReduceArgs a) {
+    const LfgcPlan& p = a.plan;
+    const int K0 = p.E + p.C;
+    const int n0 = p.H * K0 + p.H;                     // layer 0: weights then bias
+    const int n1 = p.H * p.H + p.H;
+    const int total = n0 + (p.L - 1) * n1 + p.H + 1;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        int src;
+        float* dst;
+        if (idx < n0) {
+            if (idx < p.H * K0) {
+                const int row = idx / K0, c = idx % K0;
+                src = row * p.K0R + a.col_of_src[c];
+                dst = a.dw[0] + idx;
+            } else {
+                const int r = idx - p.H * K0;
+                src = p.HP * p.K0R + r;
+                dst = a.db[0] + r;
+            }
+        } else if (idx < n0 + (p.L - 1) * n1) {
+            const int l = 1 + (idx - n0) / n1, o = (idx - n0) % n1;
+            const int base = lfgc_slab_layer_off(p, l);
+            if (o < p.H * p.H) {
+                src = base + (o / p.H) * p.HP + (o % p.H);
+                dst = a.dw[l] + o;
+            } else {
+                src = base + p.HP * p.HP + (o - p.H * p.H);
+                dst = a.db[l] + (o - p.H * p.H);
+            }
+        } else {
+            const int o = idx - n0 - (p.L - 1) * n1;
+            const int base = lfgc_slab_layer_off(p, p.L);
+            if (o < p.H) { src = base + o; dst = a.dw[p.L] + o; }
+            else { src = base + p.HP; dst = a.db[p.L]; }
+        }
+        float s = 0.0f;
+        for (int g = 0; g < a.nslabs; ++g) s += a.slabs[(long long)g * a.slab_floats + src];
+        *dst = s;
+    }
+}
+
+template <int CH, int MT, int NF>
+static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int lds_bytes, int grid_data, int grid_w,
+                           hipStream_t stream) {
+    auto kd = lfgc_bwd_data_kernel<CH, MT, NF>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kd, dim3(grid_data), dim3(256), lds_bytes, stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    hipLaunchKernelGGL((lfgc_bwd_weight_kernel<CH, MT, NF>), dim3(grid_w), dim3(256), 0, stream, w);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}

@@ -1,14 +1,117 @@
-// lfgc_backward.hip -- backward of the fused sample + embed + MLP path (placeholder until the kernels land).
-#include "lfgc_common.h"
+// lfgc_backward.hip -- C-ABI entry for the backward of the fused path: checks, workspace carving, dispatch.
+#include "lfgc_backward.h"
+
+int lfgc_bwd_dispatch_ch8(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch16(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch24(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch32(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
+
+namespace {
+const int kMaxSlabs = 256;          // workgroups of the weight-gradient kernel (one partial slab each)
+
+struct Carve {
+    long long ntiles, nbatches;
+    int nslabs;
+    long long dstash_floats, slab_floats_total;
+};
+
+Carve carve(const LfgcPlan& p, long long n) {
+    Carve c;
+    c.nbatches = (n + LFGC_WG_SAMPLES - 1) / LFGC_WG_SAMPLES;
+    c.ntiles = c.nbatches * LFGC_WG_WAVES;
+    c.nslabs = (int)(c.ntiles < kMaxSlabs ? c.ntiles : kMaxSlabs);
+    if (c.nslabs < 1) c.nslabs = 1;
+    c.dstash_floats = c.ntiles * 64LL * (p.L * 16 * p.MT);
+    c.slab_floats_total = (long long)c.nslabs * lfgc_slab_floats(p);
+    return c;
+}
+}  // namespace
 
 extern "C" int64_t lfgc_backward_workspace_bytes(const lfgc_mlp_desc* desc, int64_t n_samples) {
     if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
-    (void)n_samples;
-    return 0;
+    if (n_samples < 0) return LFGC_E_SHAPE;
+    const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
+    const Carve c = carve(p, n_samples);
+    return (c.dstash_floats + c.slab_floats_total) * 4;
 }
 
-extern "C" int lfgc_backward_f32(const lfgc_mlp_desc*, const lfgc_positions*, const float*, int, int, int,
-                                 const float*, const float*, const float*, float*, float* const*, float* const*,
-                                 float*, void*, int64_t, lfgc_stream_t) {
-    return LFGC_E_UNSUPPORTED;
+extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
+                                 const float* grid_cl, int D, int H, int W,
+                                 const float* packed, const float* stash, const float* d_out,
+                                 float* d_grid_cl, float* const* d_weights, float* const* d_biases, float* d_pos,
+                                 void* workspace, int64_t workspace_bytes, lfgc_stream_t stream) {
+    if (!desc || !positions || !grid_cl || !packed || !stash || !d_out || !d_grid_cl || !d_weights || !d_biases)
+        return LFGC_E_NULL;
+    if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
+    if (!positions->pos) return LFGC_E_NULL;            // backward runs on explicit positions only
+    if (positions->n < 0 || D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
+    if ((((uintptr_t)grid_cl) | ((uintptr_t)packed) | ((uintptr_t)stash) | ((uintptr_t)d_grid_cl) | ((uintptr_t)workspace)) & 15)
+        return LFGC_E_ALIGN;
+    const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
+    const long long n = positions->n;
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l <= p.L; ++l)
+        if (!d_weights[l] || !d_biases[l]) return LFGC_E_NULL;
+    if (n == 0) {                                       // gradients of an empty batch are zero
+        const int K0 = p.E + p.C;
+        for (int l = 0; l <= p.L; ++l) {
+            const size_t wn = (l == 0) ? (size_t)p.H * K0 : (l == p.L ? (size_t)p.H : (size_t)p.H * p.H);
+            const size_t bn = (l == p.L) ? 1 : (size_t)p.H;
+            hipError_t e = hipMemsetAsync(d_weights[l], 0, wn * 4, st);
+            if (e == hipSuccess) e = hipMemsetAsync(d_biases[l], 0, bn * 4, st);
+            if (e != hipSuccess) return (int)e;
+        }
+        return LFGC_OK;
+    }
+    const Carve c = carve(p, n);
+    if (!workspace || workspace_bytes < (c.dstash_floats + c.slab_floats_total) * 4) return LFGC_E_WORKSPACE;
+    float* dstash = reinterpret_cast<float*>(workspace);
+    float* slabs = dstash + c.dstash_floats;
+
+    LfgcBwdArgs a;
+    a.pos = positions->pos; a.n = n;
+    a.grid = grid_cl; a.D = D; a.H = H; a.W = W; a.Cs = p.CH;
+    a.packed = packed; a.L = p.L; a.stash = stash; a.d_out = d_out;
+    a.dstash = dstash; a.d_grid = d_grid_cl; a.d_pos = d_pos; a.nbatches = c.nbatches;
+
+    LfgcWgradArgs w;
+    w.stash = stash; w.dstash = dstash; w.d_out = d_out; w.n = n; w.ntiles = c.ntiles; w.L = p.L;
+    w.slabs = slabs; w.slab_floats = lfgc_slab_floats(p);
+
+    const int tb0 = p.K0R * p.ST, tb1 = p.HP * p.ST, sc = 4 * 32 * (p.CH + 4 + 16);
+    int sw = tb0 > tb1 ? tb0 : tb1;
+    if (sc > sw) sw = sc;
+    const int lds_bytes = (p.HP + 4 + sw) * 4;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    long long grid_data = 2LL * cus;
+    if (grid_data > c.nbatches) grid_data = c.nbatches;
+
+    int rc;
+    switch (p.CH) {
+        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        default: return LFGC_E_UNSUPPORTED;
+    }
+    if (rc != LFGC_OK) return rc;
+
+    LfgcReduceArgs r;
+    r.slabs = slabs; r.nslabs = c.nslabs; r.slab_floats = w.slab_floats; r.plan = p;
+    for (int l = 0; l <= p.L; ++l) { r.dw[l] = d_weights[l]; r.db[l] = d_biases[l]; }
+    for (int i = 0; i < 64; ++i) r.col_of_src[i] = 0;
+    for (int cl = 0; cl < p.K0P; ++cl) {
+        const int src = lfgc_layer0_src_col(p, cl);
+        if (src >= 0) r.col_of_src[src] = cl;
+    }
+    const int K0 = p.E + p.C;
+    const int total = p.H * K0 + p.H + (p.L - 1) * (p.H * p.H + p.H) + p.H + 1;
+    int g = (total + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(lfgc_bwd_reduce_kernel, dim3(g), dim3(256), 0, st, r);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
 }

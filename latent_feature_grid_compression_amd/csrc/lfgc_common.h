@@ -23,10 +23,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // column) fall on 16 distinct 16-byte bank slots (stride = 4 * odd).
 // Blob (floats):  [layer0: W (HP x S0) | bias HP] [layer l=1..L-1: W (HP x S1) | bias HP]
 //                 [final: Wf HP | bf 4]
-//                 [transposed copies for backward: layer0^T (K0P x ST) , layer l^T (HP x ST)]
+//                 [transposed copies for backward: layer0^T (K0R x ST, K0R = K0P rounded to 32), layer l^T (HP x ST)]
 // ------------------------------------------------------------------------------------------------
 struct LfgcPlan {
-    int C, CH, H, HP, MT, L, NF, E, EP, K0P, KS0, KS1, S0, S1, ST;
+    int C, CH, H, HP, MT, L, NF, E, EP, K0P, K0R, KS0, KS1, S0, S1, ST;
     int blk0, blk1;          // floats per forward layer block (weights + bias)
     int off_final;           // float offset of [Wf | bf]
     int fwd_floats;          // floats of the forward part
@@ -57,7 +57,8 @@ __host__ __device__ inline LfgcPlan lfgc_make_plan(int C, int H, int L, int NF) 
     p.blk1 = p.HP * p.S1 + p.HP;
     p.off_final = p.blk0 + (L - 1) * p.blk1;
     p.fwd_floats = p.off_final + p.HP + 4;
-    p.tblk0 = p.K0P * p.ST;
+    p.K0R = lfgc_roundup(p.K0P, 32);     // layer-0 transposed image: rows padded to whole 32-row MFMA tiles
+    p.tblk0 = p.K0R * p.ST;
     p.tblk1 = p.HP * p.ST;
     p.off_t = p.fwd_floats;
     p.total_floats = p.off_t + p.tblk0 + (L - 1) * p.tblk1;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
         } else if (idx < p.off_t + p.tblk0) {                 // layer 0 transposed: [packed col][h_out]
             const int o = idx - p.off_t;
             const int cl = o / p.ST, ho = o % p.ST;
-            if (ho < p.H) {
+            if (ho < p.H && cl < p.K0P) {
                 const int src = lfgc_layer0_src_col(p, cl);
                 if (src >= 0) v = a.w[0][ho * K0 + src];
             }

@@ -1,0 +1,137 @@
+"""GPU parity tests (through the C-ABI) for the backward side of the hot path: gradients into the
+wavelet coefficients, the MLP parameters and the input positions, and one complete train step.
+
+Reference = fixtures captured from the reference's own autograd (tests/golden) and the oracle's autograd on
+seeded synthetic models.  Gradients are sums over thousands of samples accumulated in a different order
+(MFMA k-order, float atomics), so they are compared relative to the largest gradient entry of each tensor:
+max|g - g_ref| / max|g_ref| <= 2e-5 (fp32), stated per test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_torch as R
+from test_hip_forward import build_from_golden, build_synth, rel_err, GOLD, dev  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads_vs(model, ref_named, tol, what=''):
+    worst = 0.0
+    for name, p in model.named_parameters():
+        g = p.grad
+        assert g is not None, name
+        ref = ref_named[name]
+        assert tuple(g.shape) == tuple(ref.shape), name
+        e = rel_err(g.cpu().numpy(), ref)
+        worst = max(worst, e)
+        assert e <= tol, '%s %s: rel err %.3e' % (what, name, e)
+    return worst
+
+
+@pytest.mark.parametrize('name', ['fwd_c4g15h16l3.npz', 'fwd_c6g17h32l4.npz'])
+def test_backward_matches_reference_fixture(dev, name):
+    g = np.load(os.path.join(GOLD, name))
+    m = build_from_golden(g, dev).train()
+    pos = torch.from_numpy(g['pos']).to(dev).requires_grad_(True)      # training.py:99 sets requires_grad on positions
+    y = m(pos)
+    loss = torch.nn.functional.mse_loss(y.squeeze(-1), torch.from_numpy(g['target']).to(dev))
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * abs(float(g['loss']))
+    loss.backward()
+    ref = {k[5:]: g[k] for k in g.files if k.startswith('grad.')}
+    _grads_vs(m, ref, 2e-5, name)
+    assert rel_err(pos.grad.cpu().numpy(), g['grad_pos']) <= 2e-5
+
+
+@pytest.mark.parametrize('C,G,H,L,n', [
+    (16, 32, 64, 4, 16384),      # cfg 2 shape, test_vol train batch (turbulence_basic.txt: 1024 x 16)
+    (32, 64, 128, 4, 32768),     # cfg 3: mhd train step, 2048 x 16 samples
+    (22, 17, 32, 4, 5000),       # reference experiment config shape, ragged N
+    (3, 15, 100, 1, 77),         # padding everywhere, single hidden layer, N < one tile
+])
+def test_backward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n):
+    m, sm = build_synth(C, G, H, L, seed=5000 + C + G + H, dev=dev)
+    m.train()
+    rng = np.random.default_rng(C * 77 + G)
+    # training samples are voxel-lattice points (data/IndexDataset.py:90-96): use a 255^3 lattice
+    ds = R.VolumeIndexing((255, 255, 255))
+    idx = torch.from_numpy(rng.integers(0, 255, (n, 3)))
+    _, pos = ds.training_positions(idx)
+    target = torch.from_numpy(rng.uniform(-1, 1, (n,)).astype(np.float32))
+    pos_d = pos.to(dev).requires_grad_(True)
+    y = m(pos_d)
+    loss = torch.nn.functional.mse_loss(y.squeeze(-1), target.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle autograd
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    coeffs = [c.clone().requires_grad_(True) for c in sm['coeffs']]
+    ws = [w.clone().requires_grad_(True) for w in sm['weights']]
+    bs = [b.clone().requires_grad_(True) for b in sm['biases']]
+    pos_r = pos.clone().requires_grad_(True)
+    yr = R.forward(coeffs, sm['shape_array'], sm['filter_rev'], ws, bs, pos_r, 2, training=True)
+    lr = torch.nn.functional.mse_loss(yr.squeeze(-1), target)
+    lr.backward()
+    assert abs(loss.item() - lr.item()) <= 1e-5 * abs(lr.item())
+    ref = {}
+    for i, c in enumerate(coeffs):
+        ref['feature_grid.%d' % i] = c.grad.numpy()
+    for i in range(L):
+        ref['net_layers.%d.weight' % i] = ws[i].grad.numpy()
+        ref['net_layers.%d.bias' % i] = bs[i].grad.numpy()
+    ref['final_layer.weight'] = ws[L].grad.numpy()
+    ref['final_layer.bias'] = bs[L].grad.numpy()
+    _grads_vs(m, ref, 2e-5, 'C%d G%d H%d L%d' % (C, G, H, L))
+    assert rel_err(pos_d.grad.cpu().numpy(), pos_r.grad.numpy()) <= 2e-5
+
+
+def test_backward_without_input_grad_and_repeatability(dev):
+    """positions that do not require grad skip the d_pos work; parameter grads are unchanged.  Weight/bias
+    gradients are bitwise repeatable (slab reduction); grid gradients use float atomics (order-dependent)."""
+    m, _ = build_synth(16, 16, 32, 2, seed=77, dev=dev)
+    m.train()
+    pos = (torch.rand(3000, 3, device=dev) * 2 - 1)
+    outs = []
+    for req in (True, False, False):
+        m.zero_grad()
+        p = pos.clone().requires_grad_(req)
+        m(p).square().mean().backward()
+        outs.append({k: v.grad.clone() for k, v in m.named_parameters()})
+    for k in outs[0]:
+        if k.startswith('feature_grid'):
+            assert rel_err(outs[1][k].cpu().numpy(), outs[0][k].cpu().numpy()) <= 1e-5
+        else:
+            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[1][k], outs[2][k]), k
+
+
+def test_train_step_matches_reference(dev):
+    """training/training.py:95-138 with the reference's Adam(lr=0.008): loss, gradients and updated parameters."""
+    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_f_interpolation
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    g = np.load(os.path.join(GOLD, 'trainstep_small.npz'))
+    gm = np.load(os.path.join(GOLD, 'fwd_c4g15h16l3.npz'))
+    m = build_from_golden(gm, dev).train()          # same seeded model as the fixture's "before" state
+    for k, p in m.state_dict().items():
+        assert np.array_equal(p.cpu().numpy(), g['before.' + k]), k
+    vol = torch.from_numpy(g['volume']).to(dev)
+    ds = IndexDataset(vol.cpu(), 16)
+    raw = torch.from_numpy(g['raw']).to(dev)
+    _, norm = ds.positions_for(raw)
+    assert np.array_equal(norm.cpu().numpy(), g['norm'])
+    opt = torch.optim.Adam(m.parameters(), lr=0.008)
+    norm.requires_grad = True
+    opt.zero_grad()
+    pred = m(norm).squeeze(-1)
+    gt = trilinear_f_interpolation(raw, vol, ds.min_idx, ds.max_idx, ds.vol_res)
+    assert np.array_equal(gt.cpu().numpy(), g['gt'])
+    assert rel_err(pred.detach().cpu().numpy(), g['pred']) <= 1e-5
+    loss = torch.nn.MSELoss()(pred, gt)
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5 * float(g['loss'])
+    loss.backward()
+    opt.step()
+    for k, p in m.state_dict().items():
+        if k.startswith('filter.'):
+            continue
+        # first Adam step moves every entry by lr * g / (|g| + eps): compare to 5 % of lr
+        assert np.abs(p.cpu().numpy() - g['after.' + k]).max() <= 0.05 * 0.008, k
