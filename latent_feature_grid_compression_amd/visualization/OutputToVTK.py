@@ -151,7 +151,8 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
     mine = torch.zeros((max_x, res[1], res[2]), dtype=torch.float32, device=device)
     if e > b:
         slab_fn(b, e, mine[:e - b])
-    dist.all_gather_into_tensor(gathered, mine, group=group)
+    # concatenated (world * max_x, Y, Z) form: accepted by both RCCL and gloo
+    dist.all_gather_into_tensor(gathered.view(world * max_x, res[1], res[2]), mine, group=group)
     if all(e_ - b_ == max_x for b_, e_ in parts):
         return gathered.view(world * max_x, res[1], res[2])[:res[0]]
     return torch.cat([gathered[r, :e_ - b_] for r, (b_, e_) in enumerate(parts)], 0)

@@ -1,0 +1,206 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/lfgc.h declares (no compute calls
+without a GPU), the host-side mirror of the reference interface (constructor, attribute names, state_dict
+keys/shapes/order, filter buffers, shape arrays) matches the reference fixtures, the HIP path refuses CPU
+tensors, and the multi-rank reconstruction driver (slab partition + one all-gather) is exercised with
+world_size 2 over gloo."""
+import ctypes
+import json
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    from latent_feature_grid_compression_amd.build import build
+    return build(verbose=False)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    header = open(os.path.join(ROOT, 'include', 'lfgc.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(lfgc_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(built_lib)
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'liblfgc.so does not export %s' % name
+    from latent_feature_grid_compression_amd import _lib
+    assert set(_lib.SIGNATURES) == declared          # the ctypes binding covers the whole header
+    lib.lfgc_version.restype = ctypes.c_int
+    assert lib.lfgc_version() == 100
+
+
+def test_pure_host_entry_points(built_lib):
+    """Entry points that touch no device: plan sizes, support matrix, error strings, argument validation."""
+    from latent_feature_grid_compression_amd import _lib
+    lib = _lib.load()
+    ok = _lib.MlpDesc(32, 128, 4, 2, 3, 1)
+    assert lib.lfgc_mlp_supported(ctypes.byref(ok)) == 1
+    for bad in (_lib.MlpDesc(64, 128, 4, 2, 3, 1), _lib.MlpDesc(32, 256, 4, 2, 3, 1), _lib.MlpDesc(32, 128, 9, 2, 3, 1),
+                _lib.MlpDesc(32, 128, 4, 3, 3, 1), _lib.MlpDesc(32, 128, 4, 2, 2, 1), _lib.MlpDesc(32, 128, 4, 2, 3, 2)):
+        assert lib.lfgc_mlp_supported(ctypes.byref(bad)) == 0
+        assert lib.lfgc_packed_bytes(ctypes.byref(bad)) == -3
+    assert lib.lfgc_grid_channel_stride(22) == 24 and lib.lfgc_grid_channel_stride(32) == 32
+    # packed blob: forward blocks + final + transposed blocks (csrc/lfgc_common.h)
+    HP, K0P, K0R, L = 128, 48, 64, 4
+    fwd = HP * (K0P + 4) + HP + (L - 1) * (HP * (HP + 4) + HP) + HP + 4
+    tr = K0R * (HP + 4) + (L - 1) * HP * (HP + 4)
+    assert lib.lfgc_packed_bytes(ctypes.byref(ok)) == 4 * (fwd + tr)
+    # stash: whole workgroup batches of 4 x 32 samples, 64 lanes x (KS0 + L*16*MT) floats per tile
+    assert lib.lfgc_stash_bytes(ctypes.byref(ok), 1) == 4 * 4 * 64 * (24 + 4 * 64)
+    assert lib.lfgc_stash_bytes(ctypes.byref(ok), 32768) == 4 * 1024 * 64 * (24 + 4 * 64)
+    assert lib.lfgc_backward_workspace_bytes(ctypes.byref(ok), 0) >= 0
+    assert lib.lfgc_error_string(0) == b'ok'
+    assert b'NULL' in lib.lfgc_error_string(-1)
+    # NULL / shape errors are reported before anything is launched
+    assert lib.lfgc_idwt_level_f32(None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 0, 1, None) == -1
+    assert lib.lfgc_forward_f32(ctypes.byref(ok), None, None, 1, 1, 1, None, 0, None, None, None) == -1
+    assert lib.lfgc_gt_interp_f32(None, None, None, None, None, 0, 1, 1, 1, None, None) == -1
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from latent_feature_grid_compression_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.LfgcError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_module_mirrors_reference_interface():
+    from latent_feature_grid_compression_amd.model.model_utils import setup_model
+    from latent_feature_grid_compression_amd.model.Feature_Grid_Model import Feature_Grid_Model
+    from latent_feature_grid_compression_amd import _lib
+    g = np.load(os.path.join(GOLD, 'fwd_cfg1_c16g16h32l2.npz'))
+    m = setup_model(3, 32, 1, 2, 'fourier', 2, '', 0.1, 0.9, 'db2', 16, 16, '')
+    assert isinstance(m, Feature_Grid_Model)
+    ref_keys = [k[3:] for k in g.files if k.startswith('sd.')]
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(ref_keys)
+    # order as the reference registers them: filter buffers, feature_grid.*, net_layers.*, final_layer.*
+    assert list(sd.keys())[:2] == ['filter.filter_fwd', 'filter.filter_rev']
+    assert [n for n, _ in m.named_parameters()] == ['feature_grid.0', 'feature_grid.1', 'feature_grid.2',
+                                                    'net_layers.0.weight', 'net_layers.0.bias', 'net_layers.1.weight',
+                                                    'net_layers.1.bias', 'final_layer.weight', 'final_layer.bias']
+    for k in ref_keys:
+        assert tuple(sd[k].shape) == g['sd.' + k].shape, k
+    assert np.array_equal(sd['filter.filter_fwd'].numpy(), g['sd.filter.filter_fwd'])
+    assert np.array_equal(sd['filter.filter_rev'].numpy(), g['sd.filter.filter_rev'])
+    assert np.array_equal(m.shape_array, g['shape_array'])
+    assert (m.input_channel, m.hidden_width, m.output_channel, m.num_layer, m.d_in) == (31, 32, 1, 2, 3)
+    assert all(isinstance(d, torch.nn.Identity) for d in m.drop) and len(m.drop) == 3
+    m.load_state_dict({k: torch.from_numpy(g['sd.' + k]) for k in ref_keys})      # reference checkpoints load
+    assert float(m.save_dropvalues_on_grid('cpu')) == 0.0 and m.remove_drop_layers('cpu') is None
+    with pytest.raises(_lib.LfgcError, match='no CPU fallback'):
+        m(torch.zeros(8, 3))                                                        # the hot path is GPU-only
+
+
+def test_host_encode_matches_reference_coefficients():
+    """Init-time encode_volume on host tensors reproduces the reference's coefficient tensors and level shapes."""
+    from latent_feature_grid_compression_amd.model.Feature_Grid_Model import Feature_Grid_Model
+    from latent_feature_grid_compression_amd.model.Feature_Embedding import FourierEmbedding
+    from latent_feature_grid_compression_amd.wavelet_transform.Torch_Wavelet_Transform import WaveletFilter3d, dwt_max_level
+    for G in (15, 16, 17):
+        g = np.load(os.path.join(GOLD, 'dwt_roundtrip_%d.npz' % G))
+        m = Feature_Grid_Model(FourierEmbedding(2, 3), torch.from_numpy(g['input']), None, WaveletFilter3d('db2'),
+                               hidden_channel=4, num_layer=1)
+        assert np.array_equal(m.shape_array, g['shape_array'])
+        for i, p in enumerate(m.feature_grid):
+            assert np.array_equal(p.detach().numpy(), g['coeff%d' % i]), (G, i)
+    with open(os.path.join(GOLD, 'levels_table.json')) as f:
+        table = json.load(f)
+    with open(os.path.join(GOLD, 'pywt_db2.json')) as f:
+        pw = json.load(f)
+    for n, lv in pw['dwt_max_level_flen4'].items():
+        assert dwt_max_level(int(n), 4) == lv
+    m = Feature_Grid_Model(FourierEmbedding(2, 3), torch.zeros(1, 64, 64, 64), None, WaveletFilter3d('db2'),
+                           hidden_channel=4, num_layer=1)
+    assert np.asarray(m.shape_array).tolist() == table['64']['shape_array']
+    m3 = Feature_Grid_Model(FourierEmbedding(2, 3), torch.zeros(1, 128, 128, 128), None, WaveletFilter3d('db2'),
+                            hidden_channel=4, num_layer=1, num_levels=3)              # BASELINE cfg 5: 3 levels on 128^3
+    assert np.asarray(m3.shape_array).tolist() == table['128_levels3']['shape_array']
+    assert [list(p.shape) for p in m3.feature_grid] == table['128_levels3']['coeff_shapes']
+
+
+def test_embedder_and_dataset_arithmetic():
+    from latent_feature_grid_compression_amd.model.Feature_Embedding import FourierEmbedding
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    g = np.load(os.path.join(GOLD, 'fwd_c4g15h16l3.npz'))
+    emb = FourierEmbedding(2, 3)
+    assert emb.out_dim == 12
+    assert np.array_equal(emb.embed(torch.from_numpy(g['pos'])).numpy(), g['x0'][:, 3:15])
+    gi = np.load(os.path.join(GOLD, 'gt_interp.npz'))
+    ds = IndexDataset(torch.from_numpy(gi['vol_a']), 16)
+    raw, norm = ds.positions_for(torch.from_numpy(gi['item_raw_a']))
+    assert np.array_equal(norm.numpy(), gi['item_norm_a'])
+    big = IndexDataset((1024, 1024, 1024), 16, build_index_table=False)       # no 12.9 GB table
+    r, nrm = big[0]
+    assert r.shape == (16, 3) and float(nrm.abs().max()) <= 1.0
+
+
+def test_slab_partition_properties():
+    from latent_feature_grid_compression_amd.visualization.OutputToVTK import slab_partition
+    for res in (255, 256, 150, 33, 1024, 70):
+        for world in (1, 2, 3, 4, 8):
+            parts = slab_partition(res, world, 32)
+            assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == res
+            for (b0, e0), (b1, e1) in zip(parts[:-1], parts[1:]):
+                assert e0 == b1 and b0 % 32 == 0 and b1 % 32 == 0 and e0 >= b0
+            tiles = [((e - b) + 31) // 32 for b, e in parts]
+            assert max(tiles) - min(tiles) <= 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gloo_worker(rank, world, port, res, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    from latent_feature_grid_compression_amd.visualization.OutputToVTK import reconstruct_volume_sharded
+    ds = IndexDataset(res, 16, build_index_table=False)
+    calls = []
+
+    def slab_fn(b, e, out_view):            # stands in for the fused HIP forward of the slab
+        calls.append((b, e))
+        x = torch.arange(b, e, dtype=torch.float32).view(-1, 1, 1)
+        y = torch.arange(res[1], dtype=torch.float32).view(1, -1, 1)
+        z = torch.arange(res[2], dtype=torch.float32).view(1, 1, -1)
+        out_view.copy_(x * 10000 + y * 100 + z)
+
+    vol = reconstruct_volume_sharded(ds, None, 32, slab_fn=slab_fn, device=torch.device('cpu'))
+    torch.save({'vol': vol.clone(), 'calls': calls}, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('res,world', [((70, 9, 11), 2), ((33, 5, 4), 2), ((64, 6, 6), 2)])
+def test_sharded_reconstruction_world2_gloo(tmp_path, res, world):
+    port = _free_port()
+    mp.spawn(_gloo_worker, args=(world, port, res, str(tmp_path)), nprocs=world, join=True)
+    x = torch.arange(res[0], dtype=torch.float32).view(-1, 1, 1)
+    y = torch.arange(res[1], dtype=torch.float32).view(1, -1, 1)
+    z = torch.arange(res[2], dtype=torch.float32).view(1, 1, -1)
+    expect = x * 10000 + y * 100 + z
+    seen = []
+    for r in range(world):
+        d = torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r), weights_only=True)
+        assert torch.equal(d['vol'], expect), r                     # every rank holds the whole volume
+        seen += [tuple(c) for c in d['calls']]
+    assert sorted(seen)[0][0] == 0 and sorted(seen)[-1][1] == res[0] and len(seen) == world   # each slab evaluated once
