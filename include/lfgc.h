@@ -53,19 +53,23 @@ const char* lfgc_error_string(int code);
  *   lll        device (C, d0,d1,d2)           low band (coarse parameter or previous level's output)
  *   hf         device (C, 7, d0,d1,d2)        detail bands, sub-band s = 4a+2b+c stored at hf[:, s-1]
  *   filter_rev device (8, 4,4,4)              the module's `filter.filter_rev` buffer (fp32)
- *   out        device (C, t0,t1,t2) if !channel_last_out, else (t0,t1,t2, C_pad) with C_pad =
- *              out_channel_stride >= C (channels [C, C_pad) are written as 0)
+ *   out        device (C, t0,t1,t2)
  * Requires 2*d_a + 2 >= t_a >= 1. */
 int lfgc_idwt_level_f32(const float* lll, const float* hf, const float* filter_rev, float* out,
-                        int C, int d0, int d1, int d2, int t0, int t1, int t2,
-                        int channel_last_out, int out_channel_stride, lfgc_stream_t stream);
+                        int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
 
 /* Adjoint of lfgc_idwt_level_f32 (what autograd derives for the ops above; triggered at
  * training/training.py:137): d_lll (C,d0,d1,d2) and d_hf (C,7,d0,d1,d2) are OVERWRITTEN with the
- * gradients given d_out in the same layout as `out` above. */
+ * gradients given d_out (C, t0,t1,t2). */
 int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_rev, float* d_lll, float* d_hf,
-                            int C, int d0, int d1, int d2, int t0, int t1, int t2,
-                            int channel_last_out, int out_channel_stride, lfgc_stream_t stream);
+                            int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
+
+/* Layout conversion of a dense grid between the reference's channel-first (C, V) = decode_volume()'s output
+ * (model/Feature_Grid_Model.py:108) and the channel-last (V, channel_stride) form the sampler and the gradient
+ * scatter use (V = D*H*W voxels, channel_stride = lfgc_grid_channel_stride(C), pad channels written as 0).
+ * to_channel_last != 0: src (C,V) -> dst (V,cs); else src (V,cs) -> dst (C,V).  src != dst. */
+int lfgc_grid_layout_f32(const float* src, float* dst, int C, int64_t voxels, int channel_stride,
+                         int to_channel_last, lfgc_stream_t stream);
 
 /* One forward-DWT level (init only).  Replaces _WaveletFilterNd.encode incl. _pad_for_forward
  * (wavelet_transform/Torch_Wavelet_Transform.py:59-67, :75-89): zero-pad (2, 2 + odd) per axis,

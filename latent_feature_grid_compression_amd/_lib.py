@@ -31,8 +31,9 @@ _PP = POINTER(c_void_p)
 SIGNATURES = {
     'lfgc_version': (c_int, []),
     'lfgc_error_string': (c_char_p, [c_int]),
-    'lfgc_idwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
-    'lfgc_idwt_level_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'lfgc_idwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'lfgc_idwt_level_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'lfgc_grid_layout_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     'lfgc_dwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'lfgc_mlp_supported': (c_int, [POINTER(MlpDesc)]),
     'lfgc_grid_channel_stride': (c_int, [c_int]),

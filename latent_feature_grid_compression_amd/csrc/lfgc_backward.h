@@ -483,16 +483,21 @@ struct LfgcReduceArgs {
     int col_of_src[64];        // layer 0: packed column that holds original column c
 };
 
-// d_weights / d_biases in nn.Linear layout = sum over workgroup slabs.
+// d_weights / d_biases in nn.Linear layout = sum over workgroup slabs.  A block owns 64 consecutive output
+// elements; its 4 waves each sum a quarter of the slabs (coalesced 256-B rows), the quarters are combined in a
+// fixed order through LDS, so the result is bitwise repeatable.
 static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcReduceArgs a) {
     const LfgcPlan& p = a.plan;
     const int K0 = p.E + p.C;
     const int n0 = p.H * K0 + p.H;                     // layer 0: weights then bias
     const int n1 = p.H * p.H + p.H;
     const int total = n0 + (p.L - 1) * n1 + p.H + 1;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-        int src;
-        float* dst;
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;
+    int src = 0;
+    float* dst = nullptr;
+    if (idx < total) {
         if (idx < n0) {
             if (idx < p.H * K0) {
                 const int row = idx / K0, c = idx % K0;
@@ -504,25 +509,30 @@ static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcR
                 dst = a.db[0] + r;
             }
         } else if (idx < n0 + (p.L - 1) * n1) {
-            const int l = 1 + (idx - n0) / n1, o = (idx - n0) % n1;
+            const int l = 1 + (idx - n0) / n1, oo = (idx - n0) % n1;
             const int base = lfgc_slab_layer_off(p, l);
-            if (o < p.H * p.H) {
-                src = base + (o / p.H) * p.HP + (o % p.H);
-                dst = a.dw[l] + o;
+            if (oo < p.H * p.H) {
+                src = base + (oo / p.H) * p.HP + (oo % p.H);
+                dst = a.dw[l] + oo;
             } else {
-                src = base + p.HP * p.HP + (o - p.H * p.H);
-                dst = a.db[l] + (o - p.H * p.H);
+                src = base + p.HP * p.HP + (oo - p.H * p.H);
+                dst = a.db[l] + (oo - p.H * p.H);
             }
         } else {
-            const int o = idx - n0 - (p.L - 1) * n1;
+            const int oo = idx - n0 - (p.L - 1) * n1;
             const int base = lfgc_slab_layer_off(p, p.L);
-            if (o < p.H) { src = base + o; dst = a.dw[p.L] + o; }
+            if (oo < p.H) { src = base + oo; dst = a.dw[p.L] + oo; }
             else { src = base + p.HP; dst = a.db[p.L]; }
         }
-        float s = 0.0f;
-        for (int g = 0; g < a.nslabs; ++g) s += a.slabs[(long long)g * a.slab_floats + src];
-        *dst = s;
     }
+    float s = 0.0f;
+    if (idx < total) {
+        const float* sp = a.slabs + src;
+        for (int g = q; g < a.nslabs; g += 4) s += sp[(long long)g * a.slab_floats];
+    }
+    part[q][o] = s;
+    __syncthreads();
+    if (q == 0 && idx < total) *dst = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
 }
 
 template <int CH, int MT, int NF>

@@ -109,8 +109,7 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     }
     const int K0 = p.E + p.C;
     const int total = p.H * K0 + p.H + (p.L - 1) * (p.H * p.H + p.H) + p.H + 1;
-    int g = (total + 255) / 256;
-    if (g > 1024) g = 1024;
+    const int g = (total + 63) / 64;
     hipLaunchKernelGGL(lfgc_bwd_reduce_kernel, dim3(g), dim3(256), 0, st, r);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;

@@ -45,37 +45,54 @@ def grid_channel_stride(C: int) -> int:
 
 # ---- wavelet levels ------------------------------------------------------------------------------------
 
-def idwt_level(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, target: Sequence[int],
-               channel_last: bool = False) -> torch.Tensor:
-    """lll (C,d0,d1,d2), hf (C,7,d0,d1,d2) -> (C,t0,t1,t2) or channel-last (t0,t1,t2,Cs)."""
+def idwt_level(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, target: Sequence[int]) -> torch.Tensor:
+    """lll (C,d0,d1,d2), hf (C,7,d0,d1,d2) -> (C,t0,t1,t2)."""
     _require_hip(lll, hf, filter_rev)
     lll, hf, filter_rev = _f32c(lll), _f32c(hf), _f32c(filter_rev)
     C, d0, d1, d2 = lll.shape
     if tuple(hf.shape) != (C, 7, d0, d1, d2):
         raise ValueError('detail bands %s do not match low band %s' % (tuple(hf.shape), tuple(lll.shape)))
     t = [int(v) for v in target]
-    cs = grid_channel_stride(C) if channel_last else C
-    out = torch.empty((t[0], t[1], t[2], cs) if channel_last else (C, t[0], t[1], t[2]),
-                      dtype=torch.float32, device=lll.device)
+    out = torch.empty((C, t[0], t[1], t[2]), dtype=torch.float32, device=lll.device)
     check(_lib.load().lfgc_idwt_level_f32(lll.data_ptr(), hf.data_ptr(), filter_rev.data_ptr(), out.data_ptr(),
-                                          C, d0, d1, d2, t[0], t[1], t[2], int(channel_last), cs, _stream(lll)),
-          'lfgc_idwt_level_f32')
+                                          C, d0, d1, d2, t[0], t[1], t[2], _stream(lll)), 'lfgc_idwt_level_f32')
     return out
 
 
-def idwt_level_bwd(d_out: torch.Tensor, filter_rev: torch.Tensor, C: int, d: Sequence[int], target: Sequence[int],
-                   channel_last: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+def idwt_level_bwd(d_out: torch.Tensor, filter_rev: torch.Tensor, d: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """d_out (C,t0,t1,t2) -> (d_lll (C,d0,d1,d2), d_hf (C,7,d0,d1,d2))."""
     _require_hip(d_out, filter_rev)
     d_out, filter_rev = _f32c(d_out), _f32c(filter_rev)
+    C, t0, t1, t2 = d_out.shape
     d = [int(v) for v in d]
-    t = [int(v) for v in target]
-    cs = grid_channel_stride(C) if channel_last else C
     d_lll = torch.empty((C, d[0], d[1], d[2]), dtype=torch.float32, device=d_out.device)
     d_hf = torch.empty((C, 7, d[0], d[1], d[2]), dtype=torch.float32, device=d_out.device)
     check(_lib.load().lfgc_idwt_level_bwd_f32(d_out.data_ptr(), filter_rev.data_ptr(), d_lll.data_ptr(), d_hf.data_ptr(),
-                                              C, d[0], d[1], d[2], t[0], t[1], t[2], int(channel_last), cs, _stream(d_out)),
-          'lfgc_idwt_level_bwd_f32')
+                                              C, d[0], d[1], d[2], t0, t1, t2, _stream(d_out)), 'lfgc_idwt_level_bwd_f32')
     return d_lll, d_hf
+
+
+def to_channel_last(grid_cf: torch.Tensor) -> torch.Tensor:
+    """(C,D,H,W) -> (D,H,W,Cs), Cs = C rounded up to 8, pad channels zero."""
+    _require_hip(grid_cf)
+    grid_cf = _f32c(grid_cf)
+    C, D, H, W = grid_cf.shape
+    cs = grid_channel_stride(C)
+    out = torch.empty((D, H, W, cs), dtype=torch.float32, device=grid_cf.device)
+    check(_lib.load().lfgc_grid_layout_f32(grid_cf.data_ptr(), out.data_ptr(), C, D * H * W, cs, 1, _stream(grid_cf)),
+          'lfgc_grid_layout_f32')
+    return out
+
+
+def to_channel_first(grid_cl: torch.Tensor, C: int) -> torch.Tensor:
+    """(D,H,W,Cs) -> (C,D,H,W)."""
+    _require_hip(grid_cl)
+    grid_cl = _f32c(grid_cl)
+    D, H, W, cs = grid_cl.shape
+    out = torch.empty((C, D, H, W), dtype=torch.float32, device=grid_cl.device)
+    check(_lib.load().lfgc_grid_layout_f32(grid_cl.data_ptr(), out.data_ptr(), C, D * H * W, cs, 0, _stream(grid_cl)),
+          'lfgc_grid_layout_f32')
+    return out
 
 
 def dwt_out_shape(n: Sequence[int]) -> List[int]:
@@ -98,14 +115,14 @@ def dwt_level(data: torch.Tensor, filter_fwd: torch.Tensor) -> torch.Tensor:
 
 def decode_levels(coeffs: Sequence[torch.Tensor], shape_array, filter_rev: torch.Tensor,
                   channel_last: bool) -> torch.Tensor:
-    """All IDWT levels (model/Feature_Grid_Model.py:102-108, drop layers already applied by the caller)."""
-    restored = coeffs[0]
-    n_levels = len(coeffs) - 1
-    if n_levels == 0:
+    """All IDWT levels (model/Feature_Grid_Model.py:102-108, drop layers already applied by the caller);
+    optionally followed by the conversion to the sampler's channel-last layout."""
+    if len(coeffs) < 2:
         raise ValueError('a wavelet-coded grid needs at least one detail level')
-    for i, (hf, shape) in enumerate(zip(coeffs[1:], shape_array)):
-        restored = idwt_level(restored, hf, filter_rev, shape, channel_last=(channel_last and i == n_levels - 1))
-    return restored
+    restored = coeffs[0]
+    for hf, shape in zip(coeffs[1:], shape_array):
+        restored = idwt_level(restored, hf, filter_rev, shape)
+    return to_channel_last(restored) if channel_last else restored
 
 
 class DecodeVolumeFn(torch.autograd.Function):
@@ -125,11 +142,9 @@ class DecodeVolumeFn(torch.autograd.Function):
         C = ctx.dims[0][0]
         n_levels = len(ctx.dims) - 1
         grads = [None] * len(ctx.dims)
-        g = d_out
+        g = to_channel_first(d_out, C) if ctx.channel_last else d_out
         for lvl in range(n_levels, 0, -1):
-            d = ctx.dims[lvl][2:]
-            g, d_hf = idwt_level_bwd(g, ctx.filter_rev, C, d, ctx.shape_array[lvl - 1],
-                                     channel_last=(ctx.channel_last and lvl == n_levels))
+            g, d_hf = idwt_level_bwd(g, ctx.filter_rev, ctx.dims[lvl][2:])
             grads[lvl] = d_hf
         grads[0] = g
         return (None, None, None) + tuple(grads)

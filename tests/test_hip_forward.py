@@ -137,15 +137,15 @@ def test_wavelet_noncubic_and_adjoint(dev):
     ref = R.wavelet_decode(data, g['shape'], torch.from_numpy(fl['filter_rev']))
     ref.backward(d_out.unsqueeze(0))
     d = g['coeffs'].shape[-3:]
-    for cl in (False, True):
-        if cl:
-            dd = torch.zeros(*d_out.shape[1:], 8)
-            dd[..., :2] = d_out.permute(1, 2, 3, 0)
-        else:
-            dd = d_out
-        d_lll, d_hf = ops.idwt_level_bwd(dd.to(dev), frev, 2, d, g['shape'], channel_last=cl)
-        assert np.abs(d_lll.cpu().numpy() - data.grad[0, :, 0].numpy()).max() < 5e-6
-        assert np.abs(d_hf.cpu().numpy() - data.grad[0, :, 1:].numpy()).max() < 5e-6
+    d_lll, d_hf = ops.idwt_level_bwd(d_out.to(dev), frev, d)
+    assert np.abs(d_lll.cpu().numpy() - data.grad[0, :, 0].numpy()).max() < 5e-6
+    assert np.abs(d_hf.cpu().numpy() - data.grad[0, :, 1:].numpy()).max() < 5e-6
+    # layout conversion round trip (channel-first <-> channel-last with zero pad channels), ragged sizes
+    x = torch.from_numpy(rng.standard_normal((22, 5, 7, 13)).astype(np.float32)).to(dev)
+    xl = ops.to_channel_last(x)
+    assert xl.shape == (5, 7, 13, 24) and torch.equal(xl[..., :22].permute(3, 0, 1, 2), x)
+    assert float(xl[..., 22:].abs().max()) == 0.0
+    assert torch.equal(ops.to_channel_first(xl, 22), x)
 
 
 FWD = ['fwd_cfg1_c16g16h32l2.npz', 'fwd_c4g15h16l3.npz', 'fwd_c6g17h32l4.npz', 'fwd_c2g32h64l4.npz']
