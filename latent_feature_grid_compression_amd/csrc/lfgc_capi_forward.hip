@@ -62,13 +62,16 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     a.n = n;
     a.grid = grid_cl; a.D = D; a.H = H; a.W = W; a.Cs = p.CH;
     a.packed = packed; a.L = p.L; a.clamp = clamp; a.out = out; a.stash = stash;
-    a.nbatches = (n + LFGC_WG_SAMPLES - 1) / LFGC_WG_SAMPLES;
-    // LDS: [Wf | bf] + either every layer block (resident, if two workgroups still fit a CU) or the largest one
+    // LDS: [Wf | bf] + every layer block (resident: 4-wave workgroups, two per CU) or a 2-deep ring of the
+    // largest block (streamed: 8-wave workgroups, one per CU).  The stash is laid out per 32-sample tile in
+    // whole 128-sample groups either way (lfgc_stash_bytes), so both builds write the same format.
     const int all_blocks = p.off_final;
     const int max_block = p.blk0 > p.blk1 ? p.blk0 : p.blk1;
     a.resident = ((p.HP + 4 + all_blocks) * 4 <= 80 * 1024) ? 1 : 0;
-    const int lds_bytes = (p.HP + 4 + (a.resident ? all_blocks : max_block)) * 4;
-    long long grid = 2LL * num_cus();
+    const int lds_bytes = (p.HP + 4 + (a.resident ? all_blocks : 2 * max_block)) * 4;
+    const int wg_samples = a.resident ? 128 : 256;
+    a.nbatches = (n + wg_samples - 1) / wg_samples;
+    long long grid = (a.resident ? 2LL : 1LL) * num_cus();
     if (grid > a.nbatches) grid = a.nbatches;
     hipStream_t st = (hipStream_t)stream;
     switch (p.CH) {

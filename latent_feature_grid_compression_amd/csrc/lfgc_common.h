@@ -91,11 +91,17 @@ __host__ __device__ inline int lfgc_layer0_src_col(const LfgcPlan& p, int cl) {
 // ------------------------------------------------------------------------------------------------
 #define LFGC_TRIG_FAST_MAX 32768.0f
 
-__device__ __forceinline__ float lfgc_reduce_pi_fast(float x, float& sign_bits) {
+// r = x - k*pi with pi = hi + mid (+ 3.4e-15 dropped: k <= 10431 inside the fast range, error < 4e-11)
+__device__ __forceinline__ float lfgc_reduce_pi_nosign(float x) {
     const float k = __builtin_rintf(x * 0.31830987334251404f);
     float r = __builtin_fmaf(-k, 3.14159274101257324f, x);          // fp32(pi)
-    r = __builtin_fmaf(-k, -8.74227765734758577e-08f, r);           // fp32(pi - hi)
-    r = __builtin_fmaf(-k, -3.4302490200117637e-15f, r);            // fp32(pi - hi - mid)
+    return __builtin_fmaf(-k, -8.74227765734758577e-08f, r);        // fp32(pi - hi)
+}
+
+__device__ __forceinline__ float lfgc_reduce_pi_fast(float x, float& sign_bits) {
+    const float k = __builtin_rintf(x * 0.31830987334251404f);
+    float r = __builtin_fmaf(-k, 3.14159274101257324f, x);
+    r = __builtin_fmaf(-k, -8.74227765734758577e-08f, r);
     const int ki = (int)k;
     sign_bits = __int_as_float(ki << 31);                           // (-1)^k as a sign bit
     return r;
@@ -156,10 +162,40 @@ __device__ __forceinline__ void lfgc_sincosf_t(float x, float& s, float& c) {
 }
 
 // SnakeAlt(a) = 0.5 a + sin(a)^2            (model/Feature_Grid_Model.py:12-13)
+// sin(a)^2 does not depend on the (-1)^k sign of the reduced sine, so the fast form skips it.
 template <bool WIDE>
 __device__ __forceinline__ float lfgc_snake_t(float a) {
-    const float s = lfgc_sinf_t<WIDE>(a);
+    float s;
+    if (WIDE) {
+        s = lfgc_sinf_t<true>(a);
+    } else {
+        s = lfgc_sin_poly(lfgc_reduce_pi_nosign(a));
+    }
     return __builtin_fmaf(s, s, 0.5f * a);
+}
+
+// Tile-level range screen for the fast path: running max of |x| (NaN/inf need no screening: they propagate
+// to NaN through the fast path exactly as libm does).
+__device__ __forceinline__ float lfgc_absmax3(float m, float a, float b) {
+    float r;   // one instruction; fmaxf() would add canonicalising v_max per operand
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+
+// Asynchronous global -> LDS copy of `nfloats` (multiple of 4) floats laid out identically on both sides
+// (LDS-DMA: no VGPR staging; each wave-instruction moves 64 lanes x 16 B to wave-uniform base + lane*16).
+// Completion: s_waitcnt vmcnt(0) in the issuing wave, then a workgroup barrier before any wave reads.
+__device__ __forceinline__ void lfgc_dma_to_lds(const float* __restrict__ gsrc, float* lds_dst, int nfloats,
+                                                int wave, int lane, int nwaves) {
+    const int nvec = nfloats >> 2;
+    for (int base = wave * 64; base < nvec; base += nwaves * 64) {
+        const int i = base + lane;
+        if (i < nvec) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(gsrc + 4 * i),
+                (__attribute__((address_space(3))) void*)(lds_dst + 4 * base), 16, 0, 0);
+        }
+    }
 }
 
 // d SnakeAlt / da = 0.5 + 2 sin a cos a

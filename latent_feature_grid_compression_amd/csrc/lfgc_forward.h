@@ -13,8 +13,9 @@
 // next layer's B operands, so activations never leave registers and never cross lanes.  With that
 // order a lane's A values for 4 consecutive k-steps are 4 consecutive floats of one W row: one
 // ds_read_b128 feeds 4 MFMAs.
-// Workgroup = 4 waves = 128 samples; weights are staged through LDS per layer (or once, if the whole
-// network fits), 2 workgroups per CU so one computes while the other stages.
+// Nets whose layer blocks all fit 80 KB of LDS: workgroup = 4 waves = 128 samples, blocks staged once, two
+// workgroups per CU.  Larger nets: workgroup = 8 waves = 256 samples, one per CU, layer blocks stream through a
+// 2-deep LDS ring by LDS-DMA (next layer in flight while the current one computes, one barrier per layer).
 #pragma once
 #include "lfgc_common.h"
 
@@ -33,7 +34,7 @@ struct LfgcFwdArgs {
     int clamp;
     float* out;                // (N)
     float* stash;              // or nullptr
-    long long nbatches;        // ceil(N / 128)
+    long long nbatches;        // ceil(N / (32 * waves per workgroup))
 };
 
 // Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile
@@ -66,8 +67,8 @@ __device__ __forceinline__ float lfgc_lattice_coord(int v, int res, int tile, fl
 // One hidden layer on a 32-sample tile held in registers.
 //   s_blk : LDS block [W (32*MT rows x S floats) | bias 32*MT]
 //   Bin   : KS activations of this lane (k order above);  Bout : 16*MT outputs (same order)
-//   stash : nullptr or this layer's slot for the tile: [(m*16 + r)][64 lanes]
-template <int KS, int MT, int S>
+//   stash : this layer's slot for the tile: [(m*16 + r)][64 lanes]  (STASH builds only)
+template <int KS, int MT, int S, bool STASH>
 __device__ __forceinline__ void lfgc_layer_fwd(const float* __restrict__ s_blk, const float (&Bin)[KS],
                                                float (&Bout)[16 * MT], float* __restrict__ stash,
                                                int j, int hh, int lane) {
@@ -91,24 +92,31 @@ __device__ __forceinline__ void lfgc_layer_fwd(const float* __restrict__ s_blk, 
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, Bin[4 * qb + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, Bin[4 * qb + 3], acc, 0, 0, 0);
         }
-        if (stash) {
+        if (STASH) {
+            // one opaque row pointer per tile + immediate offsets (r * 256 B): otherwise hipcc hoists a 64-bit
+            // address per store out of the batch loop and spills ~60 VGPRs
+            float* pm = stash + m * (16 * 64) + lane;
+            asm volatile("" : "+v"(pm));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) stash[(m * 16 + r) * 64 + lane] = acc[r];
+            for (int r = 0; r < 16; ++r) pm[r * 64] = acc[r];
         }
-        bool bad = false;
+        float amax = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bad |= lfgc_trig_out_of_range(acc[r]);
+        for (int r = 0; r < 16; r += 2) amax = lfgc_absmax3(amax, acc[r], acc[r + 1]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) Bout[16 * m + r] = lfgc_snake_t<false>(acc[r]);
-        if (__builtin_expect(__any(bad), 0)) {       // wave-uniform; a diverged model only
+        if (__builtin_expect(__any(amax > LFGC_TRIG_FAST_MAX), 0)) {       // wave-uniform; a diverged model only
 #pragma unroll
             for (int r = 0; r < 16; ++r) Bout[16 * m + r] = lfgc_snake_t<true>(acc[r]);
         }
     }
 }
 
-template <int CH, int MT, int NF>
-__global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
+// WAVES = 4: two workgroups per CU, layer blocks staged once ("resident" nets that fit 80 KB of LDS).
+// WAVES = 8: one workgroup per CU, the layer blocks stream through a 2-deep LDS ring by LDS-DMA: the block of
+//            layer t+1 is in flight while layer t computes, one barrier per layer, no exposed staging.
+template <int CH, int MT, int NF, int WAVES, bool STASH>
+__global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
     constexpr int K0P = CH + EP;
@@ -119,12 +127,15 @@ __global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
     constexpr int S1 = HP + 4;
     constexpr int BLK0 = HP * S0 + HP;
     constexpr int BLK1 = HP * S1 + HP;
+    constexpr int BLKMAX = BLK0 > BLK1 ? BLK0 : BLK1;
     constexpr int CHH = CH / 2;          // channels gathered per lane
     constexpr int EPH = EP / 2;          // scalar inputs carried per lane
+    constexpr bool STREAM = (WAVES == 8);
+    constexpr int NT = WAVES * 64;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_final = smem;               // Wf (HP) | bf (4)
-    float* s_w = smem + HP + 4;          // layer blocks
+    float* s_w = smem + HP + 4;          // resident: every layer block; streamed: ring of 2 x BLKMAX
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -136,17 +147,20 @@ __global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
 
     {   // final layer (+ every layer block when resident): staged once per workgroup
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_final);
-        for (int i = tid; i < (HP + 4) / 4; i += 256) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
-        if (a.resident) {
+        for (int i = tid; i < (HP + 4) / 4; i += NT) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
+        if (!STREAM) {
             const f32x4* srcw = reinterpret_cast<const f32x4*>(a.packed);
-            for (int i = tid; i < off_final / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = srcw[i];
+            for (int i = tid; i < off_final / 4; i += NT) reinterpret_cast<f32x4*>(s_w)[i] = srcw[i];
+        } else {
+            lfgc_dma_to_lds(a.packed, s_w, BLK0, wave, lane, WAVES);      // layer 0 of the first batch -> slot 0
         }
     }
-    __syncthreads();
+    if (!STREAM) __syncthreads();
+    unsigned step = 0;                   // streamed: layers executed so far (ring slot = step & 1)
 
     const long long N = a.n;
     for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
-        const long long tile_idx = batch * LFGC_WG_WAVES + wave;
+        const long long tile_idx = batch * WAVES + wave;
         const long long n = tile_idx * LFGC_TILE_SAMPLES + j;
         const bool valid = n < N;
         const long long nc = valid ? n : (N - 1);
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
             p2 = lfgc_lattice_coord(vz, a.res2, a.tile, a.scale2);
         }
 
-        float B[(KS0 > KS1) ? KS0 : KS1];
+        float B0[KS0];
 
         // ---- trilinear gather: lane (j, hh) interpolates channels [hh*CHH, (hh+1)*CHH) -------------
         {
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
                 }
             }
 #pragma unroll
-            for (int c = 0; c < CHH; ++c) B[c] = feat[c];
+            for (int c = 0; c < CHH; ++c) B0[c] = feat[c];
         }
 
         // ---- scalar inputs [p | sin f_k p | cos f_k p]: every lane evaluates all, keeps its half -----
@@ -242,49 +256,50 @@ __global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
             for (int t = 0; t < EPH; ++t) {
                 float lo = e[t], hi = e[EPH + t];
                 asm volatile("" : "+v"(lo), "+v"(hi));     // keep both in VGPRs: a select of two array slots would go to scratch
-                B[CHH + t] = hh ? hi : lo;
+                B0[CHH + t] = hh ? hi : lo;
             }
         }
 
         float* stash_tile = nullptr;
-        if (a.stash) {
+        if (STASH) {
             stash_tile = a.stash + tile_idx * (long long)(64 * (KS0 + L * 16 * MT));
+            {
+                float* px = stash_tile + lane;
+                asm volatile("" : "+v"(px));
 #pragma unroll
-            for (int s = 0; s < KS0; ++s) stash_tile[s * 64 + lane] = B[s];
+                for (int s = 0; s < KS0; ++s) px[s * 64] = B0[s];
+            }
             stash_tile += 64 * KS0;
         }
 
-        // ---- layer 0 -------------------------------------------------------------------------------
+        // ---- layers ------------------------------------------------------------------------------------
+        // streamed: this layer's block was put in flight one step ago: wait for my pieces, then for everyone's;
+        // the same barrier says every wave is done with the other ring slot -> prefetch the next block into it
+        auto acquire = [&](int l) -> const float* {
+            if (!STREAM) return s_w + (l == 0 ? 0 : BLK0 + (l - 1) * BLK1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const float* blk = s_w + (step & 1) * BLKMAX;
+            const int ln = (l + 1 == L) ? 0 : l + 1;
+            if (ln != 0 || batch + gridDim.x < a.nbatches) {
+                const float* src = a.packed + (ln == 0 ? 0 : BLK0 + (long long)(ln - 1) * BLK1);
+                lfgc_dma_to_lds(src, s_w + ((step + 1) & 1) * BLKMAX, ln == 0 ? BLK0 : BLK1, wave, lane, WAVES);
+            }
+            ++step;
+            return blk;
+        };
         float Bn[16 * MT];
         {
-            if (!a.resident) {
-                __syncthreads();                         // previous batch done with the buffer
-                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed);
-                for (int i = tid; i < BLK0 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
-                __syncthreads();
-            }
-            float B0[KS0];
-#pragma unroll
-            for (int s = 0; s < KS0; ++s) B0[s] = B[s];
-            lfgc_layer_fwd<KS0, MT, S0>(s_w, B0, Bn, stash_tile, j, hh, lane);
+            const float* blk = acquire(0);
+            lfgc_layer_fwd<KS0, MT, S0, STASH>(blk, B0, Bn, stash_tile, j, hh, lane);
         }
-        // ---- hidden layers 1..L-1 --------------------------------------------------------------------
         for (int l = 1; l < L; ++l) {
-            const float* blk;
-            if (a.resident) {
-                blk = s_w + BLK0 + (l - 1) * BLK1;
-            } else {
-                __syncthreads();
-                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + BLK0 + (long long)(l - 1) * BLK1);
-                for (int i = tid; i < BLK1 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
-                __syncthreads();
-                blk = s_w;
-            }
+            const float* blk = acquire(l);
             float Bi[KS1];
 #pragma unroll
             for (int s = 0; s < KS1; ++s) Bi[s] = Bn[s];
-            lfgc_layer_fwd<KS1, MT, S1>(blk, Bi, Bn, stash_tile ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr,
-                                        j, hh, lane);
+            lfgc_layer_fwd<KS1, MT, S1, STASH>(blk, Bi, Bn, STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr,
+                                               j, hh, lane);
         }
 
         // ---- final Linear (H -> 1): per-lane partial dot + exchange between the two lane halves ------
@@ -304,16 +319,27 @@ __global__ __launch_bounds__(256, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
     }
 }
 
-// Host-side launcher for one instantiation.
-template <int CH, int MT, int NF>
-static int lfgc_launch_fwd(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
-    auto kern = lfgc_fwd_kernel<CH, MT, NF>;
+// Host-side launcher for one (CH, MT) pair: picks the resident (4-wave) or streamed (8-wave) build and the
+// stash / no-stash build.
+template <int CH, int MT, int NF, int WAVES, bool STASH>
+static int lfgc_launch_fwd_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
+    auto kern = lfgc_fwd_kernel<CH, MT, NF, WAVES, STASH>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
+}
+
+template <int CH, int MT, int NF>
+static int lfgc_launch_fwd(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
+    if (a.resident) {
+        return a.stash ? lfgc_launch_fwd_one<CH, MT, NF, 4, true>(a, lds_bytes, grid, stream)
+                       : lfgc_launch_fwd_one<CH, MT, NF, 4, false>(a, lds_bytes, grid, stream);
+    }
+    return a.stash ? lfgc_launch_fwd_one<CH, MT, NF, 8, true>(a, lds_bytes, grid, stream)
+                   : lfgc_launch_fwd_one<CH, MT, NF, 8, false>(a, lds_bytes, grid, stream);
 }

@@ -211,7 +211,7 @@ extern "C" int64_t lfgc_stash_bytes(const lfgc_mlp_desc* d, int64_t n) {
     if (!lfgc_mlp_supported(d)) return LFGC_E_UNSUPPORTED;
     if (n < 0) return LFGC_E_SHAPE;
     const LfgcPlan p = lfgc_make_plan(d->grid_channels, d->hidden, d->num_layers, d->n_freqs);
-    const int64_t tiles = (n + LFGC_WG_SAMPLES - 1) / LFGC_WG_SAMPLES * LFGC_WG_WAVES;   // whole workgroup batches
+    const int64_t tiles = (n + 255) / 256 * 8;      // whole 256-sample workgroup batches of 32-sample tiles
     return tiles * (int64_t)p.stash_tile_floats * 4;
 }
 

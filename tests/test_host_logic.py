@@ -56,8 +56,8 @@ def test_pure_host_entry_points(built_lib):
     fwd = HP * (K0P + 4) + HP + (L - 1) * (HP * (HP + 4) + HP) + HP + 4
     tr = K0R * (HP + 4) + (L - 1) * HP * (HP + 4)
     assert lib.lfgc_packed_bytes(ctypes.byref(ok)) == 4 * (fwd + tr)
-    # stash: whole workgroup batches of 4 x 32 samples, 64 lanes x (KS0 + L*16*MT) floats per tile
-    assert lib.lfgc_stash_bytes(ctypes.byref(ok), 1) == 4 * 4 * 64 * (24 + 4 * 64)
+    # stash: whole workgroup batches of 8 x 32 samples, 64 lanes x (KS0 + L*16*MT) floats per tile
+    assert lib.lfgc_stash_bytes(ctypes.byref(ok), 1) == 4 * 8 * 64 * (24 + 4 * 64)
     assert lib.lfgc_stash_bytes(ctypes.byref(ok), 32768) == 4 * 1024 * 64 * (24 + 4 * 64)
     assert lib.lfgc_backward_workspace_bytes(ctypes.byref(ok), 0) >= 0
     assert lib.lfgc_error_string(0) == b'ok'
