@@ -106,6 +106,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='headline', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-check', action='store_true', help='skip the finite-output check (ablation builds)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -174,7 +175,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
-    assert tuple(vol.shape) == tuple(res) and bool(torch.isfinite(vol).all())
+    assert tuple(vol.shape) == tuple(res) and (args.no_check or bool(torch.isfinite(vol).all()))
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if my_samples > 0 else float('nan')
     total_samples = res[0] * res[1] * res[2]

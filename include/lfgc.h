@@ -173,6 +173,10 @@ int lfgc_deviation_partial_f32(const float* pred, const float* gt, int64_t n, do
 int lfgc_debug_trig_f32(const float* x, int64_t n, float* sin_out, float* cos_out, float* snake_out,
                         lfgc_stream_t stream);
 
+/* Diagnostics: the hardware v_sin_f32 path (fract(x / 2 pi) -> v_sin), NOT used by any kernel; kept so that the
+ * accuracy argument for the polynomial path can be re-measured. */
+int lfgc_debug_hwsin_f32(const float* x, int64_t n, float* out, lfgc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

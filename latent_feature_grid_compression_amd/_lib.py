@@ -7,7 +7,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, 'liblfgc.so')
+LIB_PATH = os.environ.get('LFGC_LIB_PATH') or os.path.join(PKG_DIR, 'liblfgc.so')   # override: diagnostics builds only
 LFGC_MAX_LAYERS = 8
 
 
@@ -50,6 +50,7 @@ SIGNATURES = {
                                    c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'lfgc_deviation_partial_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'lfgc_debug_trig_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'lfgc_debug_hwsin_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -44,9 +44,9 @@ def _fingerprint() -> str:
     return h.hexdigest()
 
 
-def _compile(src: str) -> str:
-    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o')
-    cmd = [_hipcc()] + FLAGS + ['-c', src, '-o', obj]
+def _compile(src: str, obj_dir: str = None, extra=()) -> str:
+    obj = os.path.join(obj_dir or OBJ_DIR, os.path.basename(src)[:-4] + '.o')
+    cmd = [_hipcc()] + FLAGS + list(extra) + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
@@ -75,6 +75,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print('[lfgc.build] built', LIB_PATH)
     return LIB_PATH
+
+
+def build_variant(out_path: str, defines, verbose: bool = True) -> str:
+    """Diagnostics: build a separate library with extra -D flags (e.g. LFGC_ABLATE=1) next to the product one."""
+    obj_dir = out_path + '.objs'
+    os.makedirs(obj_dir, exist_ok=True)
+    extra = ['-D' + d for d in defines]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(lambda s_: _compile(s_, obj_dir, extra), sources()))
+    r = subprocess.run([_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', out_path] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    if verbose:
+        print('[lfgc.build] built variant', out_path, defines)
+    return out_path
 
 
 if __name__ == '__main__':

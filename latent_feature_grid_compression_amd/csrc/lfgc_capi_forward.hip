@@ -68,7 +68,13 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     const int all_blocks = p.off_final;
     const int max_block = p.blk0 > p.blk1 ? p.blk0 : p.blk1;
     a.resident = ((p.HP + 4 + all_blocks) * 4 <= 80 * 1024) ? 1 : 0;
-    const int lds_bytes = (p.HP + 4 + (a.resident ? all_blocks : 2 * max_block)) * 4;
+    int lds_bytes = (p.HP + 4 + (a.resident ? all_blocks : 2 * max_block)) * 4;
+    a.coord_table = 0;
+    if (!a.pos) {                                       // per-axis coordinate tables behind the weight region
+        const long long tbl = 4LL * ((long long)a.res0 + a.res1 + a.res2);
+        const long long cap = a.resident ? 80 * 1024 : 160 * 1024;
+        if (lds_bytes + tbl <= cap) { a.coord_table = 1; lds_bytes += (int)tbl; }
+    }
     const int wg_samples = a.resident ? 128 : 256;
     a.nbatches = (n + wg_samples - 1) / wg_samples;
     long long grid = (a.resident ? 2LL : 1LL) * num_cus();

@@ -19,6 +19,12 @@
 #pragma once
 #include "lfgc_common.h"
 
+// Diagnostics only (tools/ablate_forward.py builds separate libraries with -DLFGC_ABLATE=mask; the shipped
+// library is always built with 0): 1 = no gather loads, 2 = activation replaced by 0.5*a, 4 = no MFMAs.
+#ifndef LFGC_ABLATE
+#define LFGC_ABLATE 0
+#endif
+
 struct LfgcFwdArgs {
     const float* pos;          // (N,3) or nullptr (lattice mode)
     long long n;               // samples
@@ -35,6 +41,7 @@ struct LfgcFwdArgs {
     float* out;                // (N)
     float* stash;              // or nullptr
     long long nbatches;        // ceil(N / (32 * waves per workgroup))
+    int coord_table;           // lattice mode: per-axis coordinate tables fit LDS (res0+res1+res2 floats)
 };
 
 // Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile
@@ -87,10 +94,14 @@ __device__ __forceinline__ void lfgc_layer_fwd(const float* __restrict__ s_blk, 
 #pragma unroll
         for (int qb = 0; qb < KS / 4; ++qb) {
             const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * qb);
+#if LFGC_ABLATE & 4
+            acc[qb & 15] += a4.x * Bin[4 * qb] + a4.y * Bin[4 * qb + 1] + a4.z * Bin[4 * qb + 2] + a4.w * Bin[4 * qb + 3];
+#else
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, Bin[4 * qb + 0], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, Bin[4 * qb + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, Bin[4 * qb + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, Bin[4 * qb + 3], acc, 0, 0, 0);
+#endif
         }
         if (STASH) {
             // one opaque row pointer per tile + immediate offsets (r * 256 B): otherwise hipcc hoists a 64-bit
@@ -103,8 +114,14 @@ __device__ __forceinline__ void lfgc_layer_fwd(const float* __restrict__ s_blk, 
         float amax = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) amax = lfgc_absmax3(amax, acc[r], acc[r + 1]);
+#if LFGC_ABLATE & 2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Bout[16 * m + r] = 0.5f * acc[r];
+        amax = 0.0f;
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) Bout[16 * m + r] = lfgc_snake_t<false>(acc[r]);
+#endif
         if (__builtin_expect(__any(amax > LFGC_TRIG_FAST_MAX), 0)) {       // wave-uniform; a diverged model only
 #pragma unroll
             for (int r = 0; r < 16; ++r) Bout[16 * m + r] = lfgc_snake_t<true>(acc[r]);
@@ -136,6 +153,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_final = smem;               // Wf (HP) | bf (4)
     float* s_w = smem + HP + 4;          // resident: every layer block; streamed: ring of 2 x BLKMAX
+    // lattice mode: coordinate of every voxel index per axis, built once per workgroup (the per-sample form
+    // costs two fp64 divisions per axis); placed behind the weight region
+    float* s_coord = s_w + (STREAM ? 2 * BLKMAX : (BLK0 + (a.L - 1) * BLK1));
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,7 +175,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
             lfgc_dma_to_lds(a.packed, s_w, BLK0, wave, lane, WAVES);      // layer 0 of the first batch -> slot 0
         }
     }
-    if (!STREAM) __syncthreads();
+    if (!a.pos && a.coord_table) {
+        const int r01 = a.res0 + a.res1, r012 = r01 + a.res2;
+        for (int i = tid; i < r012; i += NT) {
+            s_coord[i] = i < a.res0 ? lfgc_lattice_coord(i, a.res0, a.tile, a.scale0)
+                       : i < r01 ? lfgc_lattice_coord(i - a.res0, a.res1, a.tile, a.scale1)
+                                 : lfgc_lattice_coord(i - r01, a.res2, a.tile, a.scale2);
+        }
+    }
+    __syncthreads();
     unsigned step = 0;                   // streamed: layers executed so far (ring slot = step & 1)
 
     const long long N = a.n;
@@ -171,14 +199,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
             const float* pp = a.pos + 3 * nc;
             p0 = pp[0]; p1 = pp[1]; p2 = pp[2];
         } else {
-            const long long plane = (long long)a.res1 * a.res2;
-            const int vx = a.x_begin + (int)(nc / plane);
-            const int rem = (int)(nc % plane);
-            const int vy = rem / a.res2;
-            const int vz = rem % a.res2;
-            p0 = lfgc_lattice_coord(vx, a.res0, a.tile, a.scale0);
-            p1 = lfgc_lattice_coord(vy, a.res1, a.tile, a.scale1);
-            p2 = lfgc_lattice_coord(vz, a.res2, a.tile, a.scale2);
+            int vx, vy, vz;
+            if (N <= 0xffffffffLL) {                          // 32-bit index arithmetic (any slab up to 1625^3)
+                const unsigned plane = (unsigned)a.res1 * (unsigned)a.res2;
+                const unsigned un = (unsigned)nc;
+                const unsigned qx = un / plane, rem = un - qx * plane;
+                const unsigned qy = rem / (unsigned)a.res2;
+                vx = a.x_begin + (int)qx; vy = (int)qy; vz = (int)(rem - qy * (unsigned)a.res2);
+            } else {
+                const long long plane = (long long)a.res1 * a.res2;
+                vx = a.x_begin + (int)(nc / plane);
+                const long long rem = nc % plane;
+                vy = (int)(rem / a.res2); vz = (int)(rem % a.res2);
+            }
+            if (a.coord_table) {
+                p0 = s_coord[vx]; p1 = s_coord[a.res0 + vy]; p2 = s_coord[a.res0 + a.res1 + vz];
+            } else {
+                p0 = lfgc_lattice_coord(vx, a.res0, a.tile, a.scale0);
+                p1 = lfgc_lattice_coord(vy, a.res1, a.tile, a.scale1);
+                p2 = lfgc_lattice_coord(vz, a.res2, a.tile, a.scale2);
+            }
         }
 
         float B0[KS0];
@@ -204,7 +244,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
             for (int c = 0; c < CHH; ++c) feat[c] = 0.0f;
             const float* gbase = a.grid + hh * CHH;
 #pragma unroll
-            for (int corner = 0; corner < 8; ++corner) {
+            for (int corner = 0; corner < ((LFGC_ABLATE & 1) ? 0 : 8); ++corner) {
                 const int dz = corner >> 2, dy = (corner >> 1) & 1, dx = corner & 1;   // ATen order: tnw, tne, tsw, tse, bnw, ...
                 const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
                 const bool ok = in_range && xi >= 0 && xi < a.W && yi >= 0 && yi < a.H && zi >= 0 && zi < a.D;
@@ -293,13 +333,25 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
             const float* blk = acquire(0);
             lfgc_layer_fwd<KS0, MT, S0, STASH>(blk, B0, Bn, stash_tile, j, hh, lane);
         }
-        for (int l = 1; l < L; ++l) {
-            const float* blk = acquire(l);
-            float Bi[KS1];
+        // hidden layers two at a time, ping-ponging between two register arrays (no per-layer copy)
+        {
+            float Bm[16 * MT];
+            int l = 1;
+            for (; l + 1 < L; l += 2) {
+                const float* blk = acquire(l);
+                lfgc_layer_fwd<KS1, MT, S1, STASH>(blk, Bn, Bm, STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr,
+                                                   j, hh, lane);
+                blk = acquire(l + 1);
+                lfgc_layer_fwd<KS1, MT, S1, STASH>(blk, Bm, Bn, STASH ? stash_tile + (long long)(l + 1) * (64 * 16 * MT) : nullptr,
+                                                   j, hh, lane);
+            }
+            if (l < L) {
+                const float* blk = acquire(l);
+                lfgc_layer_fwd<KS1, MT, S1, STASH>(blk, Bn, Bm, STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr,
+                                                   j, hh, lane);
 #pragma unroll
-            for (int s = 0; s < KS1; ++s) Bi[s] = Bn[s];
-            lfgc_layer_fwd<KS1, MT, S1, STASH>(blk, Bi, Bn, STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr,
-                                               j, hh, lane);
+                for (int s = 0; s < KS1; ++s) Bn[s] = Bm[s];
+            }
         }
 
         // ---- final Linear (H -> 1): per-lane partial dot + exchange between the two lane halves ------

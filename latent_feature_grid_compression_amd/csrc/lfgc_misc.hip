@@ -106,6 +106,12 @@ __global__ __launch_bounds__(256) void debug_trig_kernel(const float* x, long lo
     if (i < n) { so[i] = s; co[i] = c; sn[i] = k; }
 }
 
+// hardware v_sin_f32 (input in revolutions) behind a v_fract range reduction -- measured only, not used: see DESIGN.md
+__global__ __launch_bounds__(256) void debug_hwsin_kernel(const float* x, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x[i] * 0.15915494309189535f));
+}
+
 struct PackArgs {
     const float* w[LFGC_MAX_LAYERS + 1];
     const float* b[LFGC_MAX_LAYERS + 1];
@@ -240,6 +246,14 @@ extern "C" int lfgc_debug_trig_f32(const float* x, int64_t n, float* sin_out, fl
     if (n <= 0) return n == 0 ? LFGC_OK : LFGC_E_SHAPE;
     hipLaunchKernelGGL(debug_trig_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        x, (long long)n, sin_out, cos_out, snake_out);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_debug_hwsin_f32(const float* x, int64_t n, float* out, lfgc_stream_t stream) {
+    if (!x || !out) return LFGC_E_NULL;
+    if (n <= 0) return n == 0 ? LFGC_OK : LFGC_E_SHAPE;
+    hipLaunchKernelGGL(debug_hwsin_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }

@@ -204,3 +204,38 @@ def test_sharded_reconstruction_world2_gloo(tmp_path, res, world):
         assert torch.equal(d['vol'], expect), r                     # every rank holds the whole volume
         seen += [tuple(c) for c in d['calls']]
     assert sorted(seen)[0][0] == 0 and sorted(seen)[-1][1] == res[0] and len(seen) == world   # each slab evaluated once
+
+
+_SWAP_SCRIPT = r'''
+import sys, importlib
+sys.path.insert(0, %(root)r)
+sys.path.insert(1, '/root/reference')
+for name in ('model.Feature_Grid_Model', 'model.Feature_Embedding', 'wavelet_transform.Torch_Wavelet_Transform',
+             'data.Interpolation'):
+    pkg = name.split('.')[0]
+    sys.modules[name] = importlib.import_module('latent_feature_grid_compression_amd.' + name)
+import torch
+from model.model_utils import setup_model, get_net_weights_biases       # the REFERENCE's own factory
+import latent_feature_grid_compression_amd.model.Feature_Grid_Model as ours
+m = setup_model(3, 32, 1, 4, 'fourier', 2, 'smallify', 0.1, 0.9, 'db2', 16, 15, '')
+assert type(m) is ours.Feature_Grid_Model, type(m)
+assert type(m.drop[0]).__module__ == 'model.Smallify_Dropout'            # the reference's pruning layer, plugged in
+assert [tuple(p.shape) for p in m.feature_grid] == [(16, 6, 6, 6), (16, 7, 6, 6, 6), (16, 7, 9, 9, 9)]
+w, b = get_net_weights_biases(m)
+assert len(w) == 5 and len(b) == 5
+from model.Smallify_Dropout import SmallifyLoss                          # isinstance(m, Feature_Grid_Model) inside
+loss = SmallifyLoss(1.0, 1.0)(m)
+assert torch.isfinite(loss)
+m2 = setup_model(3, 32, 1, 4, 'fourier', 2, '', 0.1, 0.9, 'db2', 16, 15, '')
+m2.load_state_dict({k: v for k, v in m2.state_dict().items()})
+print('SWAP_OK')
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='reference checkout only exists in the build container')
+def test_reference_factory_builds_our_module_after_module_swap():
+    """INTEGRATION.md route A: with our modules registered under the reference's module names, the reference's
+    own setup_model / pruning layers / losses construct and accept the HIP-backed module (host logic only)."""
+    import subprocess
+    r = subprocess.run([sys.executable, '-c', _SWAP_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=300)
+    assert 'SWAP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
