@@ -67,8 +67,11 @@ __device__ __forceinline__ void lfgc_snake_bwd(const float* __restrict__ slot, c
     }
 }
 
-template <int CH, int MT, int NF>
-__global__ __launch_bounds__(256, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs a) {
+// One workgroup per CU (WAVES = 8 when every CU gets a 256-sample batch, else 4); the transposed weight images
+// stream through a 2-deep LDS ring by LDS-DMA exactly like the forward's (image of step t+1 in flight while step
+// t computes, one barrier per step); the scatter staging aliases the ring slot that has just been consumed.
+template <int CH, int MT, int NF, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs a) {
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
     constexpr int K0P = CH + EP;
@@ -85,10 +88,13 @@ __global__ __launch_bounds__(256, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs
     constexpr int SCS = CH + 4;                  // scatter staging row stride (floats)
     constexpr int SC_WAVE = 32 * (SCS + 16);     // per wave: dfeat rows + 8 weights + 8 offsets per sample
     constexpr int SPI = 64 / CH;                 // samples covered by one atomic wave-instruction
+    constexpr int TBMAX = TB0 > TB1 ? TB0 : TB1;
+    constexpr int SLOT = TBMAX > WAVES * SC_WAVE ? TBMAX : WAVES * SC_WAVE;   // ring slot (floats)
+    constexpr int NT = WAVES * 64;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_final = smem;               // Wf (HP) | bf (4)
-    float* s_w = smem + HP + 4;          // transposed weight image of the current layer / scatter staging
+    float* s_ring = smem + HP + 4;       // 2 x SLOT: transposed weight images / scatter staging
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
@@ -100,13 +106,31 @@ __global__ __launch_bounds__(256, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs
 
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_final);
-        for (int i = tid; i < (HP + 4) / 4; i += 256) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
+        for (int i = tid; i < (HP + 4) / 4; i += NT) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
     }
+    // image sequence per batch: W_{L-1}^T, ..., W_1^T (TB1 each), then W_0^T (TB0)
+    auto image_src = [&](int l) -> const float* {
+        return l == 0 ? a.packed + off_t : a.packed + off_t + TB0 + (long long)(l - 1) * TB1;
+    };
+    lfgc_dma_to_lds(image_src(L - 1), s_ring, (L - 1) == 0 ? TB0 : TB1, wave, lane, WAVES);
     __syncthreads();
+    unsigned step = 0;
 
     const long long N = a.n;
     for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
-        const long long tile_idx = batch * LFGC_WG_WAVES + wave;
+        // the image of layer l was put in flight one step ago; after the barrier every wave is also done with the
+        // other slot, so the next image (layer l-1, or the next batch's first) goes into it
+        auto acquire = [&](int l) -> const float* {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const float* img = s_ring + (step & 1) * SLOT;
+            const int ln = (l == 0) ? L - 1 : l - 1;
+            if (l != 0 || batch + gridDim.x < a.nbatches)
+                lfgc_dma_to_lds(image_src(ln), s_ring + ((step + 1) & 1) * SLOT, ln == 0 ? TB0 : TB1, wave, lane, WAVES);
+            ++step;
+            return img;
+        };
+        const long long tile_idx = batch * WAVES + wave;
         const long long n = tile_idx * LFGC_TILE_SAMPLES + j;
         const bool valid = n < N;
         const long long nc = valid ? n : (N - 1);
@@ -129,13 +153,7 @@ __global__ __launch_bounds__(256, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs
             lfgc_snake_bwd<MT>(st_tile + 64 * KS0 + (long long)l * (64 * 16 * MT), dH, dA, lane);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[(long long)l * (64 * 16 * MT) + i * 64 + lane] = dA[i];
-            __syncthreads();
-            {
-                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_t + TB0 + (long long)(l - 1) * TB1);
-                for (int i = tid; i < TB1 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
-            }
-            __syncthreads();
-            const float* s_row = s_w + j * ST + 4 * hh;
+            const float* s_row = acquire(l) + j * ST + 4 * hh;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f32x16 acc;
@@ -154,13 +172,7 @@ __global__ __launch_bounds__(256, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs
             lfgc_snake_bwd<MT>(st_tile + 64 * KS0, dH, dA, lane);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[i * 64 + lane] = dA[i];
-            __syncthreads();
-            {
-                const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_t);
-                for (int i = tid; i < TB0 / 4; i += 256) reinterpret_cast<f32x4*>(s_w)[i] = src[i];
-            }
-            __syncthreads();
-            const float* s_row = s_w + j * ST + 4 * hh;
+            const float* s_row = acquire(0) + j * ST + 4 * hh;
 #pragma unroll
             for (int m = 0; m < TXA; ++m) {
                 if (m < TXF || a.d_pos) {            // scalar-input rows only when d_pos is wanted (wave-uniform)
@@ -194,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs
                               (fz0 >= -1.0f) && (fz0 < (float)a.D);
 
         // ---- scatter d feat into d_grid: stage [sample][channel] + per-corner weight/offset in LDS ----------
-        __syncthreads();                                  // every wave is done with the weight image
-        float* s_df = s_w + wave * SC_WAVE;               // [32][SCS]
+        __syncthreads();                                  // every wave is done with the layer-0 image: reuse its slot
+        float* s_df = s_ring + ((step - 1) & 1) * SLOT + wave * SC_WAVE;   // [32][SCS]
         float* s_cw = s_df + 32 * SCS;                    // [32][8] corner weights
         int* s_co = reinterpret_cast<int*>(s_cw + 32 * 8);   // [32][8] corner row offsets (floats)
 #pragma unroll
@@ -331,10 +343,14 @@ __device__ __forceinline__ void lfgc_load16(const float* __restrict__ base, floa
 
 // One layer's dW (+ db) over this workgroup's sample tiles.  NT = column tiles of this layer, KSIN = stash
 // registers of the input (KS0 for layer 0 where the input is the saved x0, else 16*MT pre-activations).
+// The workgroup has 8 waves: waves 0-3 and 4-7 run the same tile/column assignment on alternate sample tiles (two
+// waves per SIMD, so one wave's loads hide under the other's MFMAs); the second half hands its accumulators over
+// through LDS (`s_comb`, [4 waves][TPW*17][64]) and the first half writes the slab.
 template <int MT, int NT, bool LAYER0, int KS0>
 __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, float* __restrict__ slab_l, int ncol,
                                                  int k0p, long long per_tile, long long dper_tile,
-                                                 int lane, int wave) {
+                                                 int lane, int wave8, float* s_comb) {
+    const int half = wave8 >> 2, wave = wave8 & 3;
     constexpr int WPN = 4 / NT;                       // waves sharing one column tile
     constexpr int TPW = (MT + WPN - 1) / WPN;         // row tiles per wave
     const int n_t = wave % NT, msub = wave / NT;
@@ -363,7 +379,7 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
     const int ra = (i & 3) + 4 * (i >> 3), ha = (i >> 2) & 1;
     const long long aoff_base = (long long)l * (64 * 16 * MT) + (long long)ra * 64 + ha * 32 + 16 * kk;
 
-    for (long long t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
         float Bv[16];
         lfgc_load16(a.stash + t * per_tile + boff, Bv);
         if (LAYER0) {
@@ -399,6 +415,27 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
             }
         }
     }
+    // second half -> LDS -> first half
+    float* mine = s_comb + (long long)wave * (TPW * 17 * 64) + lane;
+    if (half == 1) {
+#pragma unroll
+        for (int tw = 0; tw < TPW; ++tw) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(tw * 17 + r) * 64] = acc[tw][r];
+            mine[(tw * 17 + 16) * 64] = dbp[tw];
+        }
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int tw = 0; tw < TPW; ++tw) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tw][r] += mine[(tw * 17 + r) * 64];
+            dbp[tw] += mine[(tw * 17 + 16) * 64];
+        }
+    }
+    __syncthreads();
+    if (half == 1) return;
     // write this workgroup's partial: dW[32m + row][32 n_t + colj], rows from the accumulator layout
     const int cj = lane & 31, hc = lane >> 5;
 #pragma unroll
@@ -417,7 +454,8 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
 }
 
 template <int CH, int MT, int NF>
-__global__ __launch_bounds__(256, 2) void lfgc_bwd_weight_kernel(const LfgcWgradArgs a) {
+__global__ __launch_bounds__(512, 2) void lfgc_bwd_weight_kernel(const LfgcWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_comb[];
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
     constexpr int K0P = CH + EP;
@@ -431,21 +469,22 @@ __global__ __launch_bounds__(256, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
     const long long dper_tile = 64LL * (L * 16 * MT);
     float* slab = a.slabs + (long long)blockIdx.x * a.slab_floats;
 
-    lfgc_wgrad_layer<MT, NT0, true, KS0>(a, 0, slab, K0R, K0P, per_tile, dper_tile, lane, wave);
+    lfgc_wgrad_layer<MT, NT0, true, KS0>(a, 0, slab, K0R, K0P, per_tile, dper_tile, lane, wave, s_comb);
     for (int l = 1; l < L; ++l) {
         float* slab_l = slab + (HP * K0R + HP) + (long long)(l - 1) * (HP * HP + HP);
-        lfgc_wgrad_layer<MT, MT, false, KS0>(a, l, slab_l, HP, K0P, per_tile, dper_tile, lane, wave);
+        lfgc_wgrad_layer<MT, MT, false, KS0>(a, l, slab_l, HP, K0P, per_tile, dper_tile, lane, wave, s_comb);
     }
 
     // final Linear: dWf[k] = sum_n dy_n H_L[n,k], dbf = sum_n dy_n.  Wave w owns column tile w.
     {
         float* slab_f = slab + (HP * K0R + HP) + (long long)(L - 1) * (HP * HP + HP);
         const int i = lane & 31, kk = lane >> 5;
+        const int half = wave >> 2, w4 = wave & 3;
         float wsum = 0.0f, bsum = 0.0f;
-        if (wave < MT) {
+        if (w4 < MT) {
             const int r = (i & 3) + 4 * (i >> 3), hb = (i >> 2) & 1;
-            const long long boff = 64LL * KS0 + (long long)(L - 1) * (64 * 16 * MT) + (long long)(wave * 16 + r) * 64 + hb * 32 + 16 * kk;
-            for (long long t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+            const long long boff = 64LL * KS0 + (long long)(L - 1) * (64 * 16 * MT) + (long long)(w4 * 16 + r) * 64 + hb * 32 + 16 * kk;
+            for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
                 float Bv[16];
                 lfgc_load16(a.stash + t * per_tile + boff, Bv);
                 bool bad = false;
@@ -468,8 +507,14 @@ __global__ __launch_bounds__(256, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
             }
             wsum += __shfl_xor(wsum, 32);
             bsum += __shfl_xor(bsum, 32);
-            if (kk == 0) slab_f[32 * wave + i] = wsum;
-            if (wave == 0 && lane == 0) slab_f[HP] = bsum;
+        }
+        if (half == 1) { s_comb[w4 * 128 + lane] = wsum; s_comb[w4 * 128 + 64 + lane] = bsum; }
+        __syncthreads();
+        if (half == 0 && w4 < MT) {
+            wsum += s_comb[w4 * 128 + lane];
+            bsum += s_comb[w4 * 128 + 64 + lane];
+            if (kk == 0) slab_f[32 * w4 + i] = wsum;
+            if (w4 == 0 && lane == 0) slab_f[HP] = bsum;
         }
     }
 }
@@ -535,18 +580,40 @@ static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcR
     if (q == 0 && idx < total) *dst = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
 }
 
-template <int CH, int MT, int NF>
-static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int lds_bytes, int grid_data, int grid_w,
-                           hipStream_t stream) {
-    auto kd = lfgc_bwd_data_kernel<CH, MT, NF>;
+template <int CH, int MT, int NF, int WAVES>
+static int lfgc_launch_bwd_data(const LfgcBwdArgs& a, int lds_bytes, int grid_data, hipStream_t stream) {
+    auto kd = lfgc_bwd_data_kernel<CH, MT, NF, WAVES>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kd, dim3(grid_data), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kd, dim3(grid_data), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();
-    hipLaunchKernelGGL((lfgc_bwd_weight_kernel<CH, MT, NF>), dim3(grid_w), dim3(256), 0, stream, w);
+    return LFGC_OK;
+}
+
+// waves = waves per workgroup of the data kernel (4 or 8, chosen by the caller together with a.nbatches)
+template <int CH, int MT, int NF>
+static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int waves, int lds_bytes, int grid_data,
+                           int grid_w, hipStream_t stream) {
+    const int rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8>(a, lds_bytes, grid_data, stream)
+                              : lfgc_launch_bwd_data<CH, MT, NF, 4>(a, lds_bytes, grid_data, stream);
+    if (rc != LFGC_OK) return rc;
+    {
+        constexpr int K0R_ = (CH + (3 + 6 * NF + 7) / 8 * 8 + 31) / 32 * 32;
+        constexpr int NT0_ = K0R_ / 32;
+        constexpr int TPW0 = (MT + 4 / NT0_ - 1) / (4 / NT0_), TPW1 = (MT + 4 / MT - 1) / (4 / MT);
+        constexpr int TPWM = TPW0 > TPW1 ? TPW0 : TPW1;
+        const int comb_bytes = 4 * TPWM * 17 * 64 * 4;
+        auto kw = lfgc_bwd_weight_kernel<CH, MT, NF>;
+        if (comb_bytes > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kw),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, comb_bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kw, dim3(grid_w), dim3(512), comb_bytes, stream, w);
+    }
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }

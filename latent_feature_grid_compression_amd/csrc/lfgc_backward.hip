@@ -1,10 +1,10 @@
 // lfgc_backward.hip -- C-ABI entry for the backward of the fused path: checks, workspace carving, dispatch.
 #include "lfgc_backward.h"
 
-int lfgc_bwd_dispatch_ch8(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
-int lfgc_bwd_dispatch_ch16(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
-int lfgc_bwd_dispatch_ch24(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
-int lfgc_bwd_dispatch_ch32(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch8(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch16(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch24(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch32(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
 
 namespace {
 const int kMaxSlabs = 256;          // workgroups of the weight-gradient kernel (one partial slab each)
@@ -17,8 +17,8 @@ struct Carve {
 
 Carve carve(const LfgcPlan& p, long long n) {
     Carve c;
-    c.nbatches = (n + LFGC_WG_SAMPLES - 1) / LFGC_WG_SAMPLES;
-    c.ntiles = c.nbatches * LFGC_WG_WAVES;
+    c.nbatches = (n + 255) / 256;                      // whole 256-sample groups, like the forward's stash
+    c.ntiles = c.nbatches * 8;
     c.nslabs = (int)(c.ntiles < kMaxSlabs ? c.ntiles : kMaxSlabs);
     if (c.nslabs < 1) c.nslabs = 1;
     c.dstash_floats = c.ntiles * 64LL * (p.L * 16 * p.MT);
@@ -72,29 +72,33 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     a.pos = positions->pos; a.n = n;
     a.grid = grid_cl; a.D = D; a.H = H; a.W = W; a.Cs = p.CH;
     a.packed = packed; a.L = p.L; a.stash = stash; a.d_out = d_out;
-    a.dstash = dstash; a.d_grid = d_grid_cl; a.d_pos = d_pos; a.nbatches = c.nbatches;
+    a.dstash = dstash; a.d_grid = d_grid_cl; a.d_pos = d_pos;
 
     LfgcWgradArgs w;
     w.stash = stash; w.dstash = dstash; w.d_out = d_out; w.n = n; w.ntiles = c.ntiles; w.L = p.L;
     w.slabs = slabs; w.slab_floats = lfgc_slab_floats(p);
 
-    const int tb0 = p.K0R * p.ST, tb1 = p.HP * p.ST, sc = 4 * 32 * (p.CH + 4 + 16);
-    int sw = tb0 > tb1 ? tb0 : tb1;
-    if (sc > sw) sw = sc;
-    const int lds_bytes = (p.HP + 4 + sw) * 4;
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-    long long grid_data = 2LL * cus;
-    if (grid_data > c.nbatches) grid_data = c.nbatches;
+    // data kernel: one workgroup per CU, 8 waves once every CU gets a 256-sample batch, else 4 (tiles beyond the
+    // last whole 128-sample group are never touched: the stash covers whole 256-sample groups, lfgc_stash_bytes)
+    const int waves = ((n + 255) / 256 >= cus) ? 8 : 4;
+    a.nbatches = c.nbatches * (8 / waves);              // same tile range as the forward wrote
+    const int tb0 = p.K0R * p.ST, tb1 = p.HP * p.ST, sc = waves * 32 * (p.CH + 4 + 16);
+    int slot = tb0 > tb1 ? tb0 : tb1;
+    if (sc > slot) slot = sc;
+    const int lds_bytes = (p.HP + 4 + 2 * slot) * 4;
+    long long grid_data = cus;
+    if (grid_data > a.nbatches) grid_data = a.nbatches;
 
     int rc;
     switch (p.CH) {
-        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
         default: return LFGC_E_UNSUPPORTED;
     }
     if (rc != LFGC_OK) return rc;

@@ -75,8 +75,10 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
         const long long cap = a.resident ? 80 * 1024 : 160 * 1024;
         if (lds_bytes + tbl <= cap) { a.coord_table = 1; lds_bytes += (int)tbl; }
     }
-    const int wg_samples = a.resident ? 128 : 256;
-    a.nbatches = (n + wg_samples - 1) / wg_samples;
+    // streamed nets: 8-wave workgroups once every CU gets at least one 256-sample batch, else 4-wave ones
+    a.waves = (!a.resident && (n + 255) / 256 >= num_cus()) ? 8 : 4;
+    // always whole 256-sample groups of tiles, so the stash covers the same tile range whichever build runs
+    a.nbatches = (n + 255) / 256 * (8 / a.waves);
     long long grid = (a.resident ? 2LL : 1LL) * num_cus();
     if (grid > a.nbatches) grid = a.nbatches;
     hipStream_t st = (hipStream_t)stream;

@@ -41,6 +41,7 @@ struct LfgcFwdArgs {
     float* out;                // (N)
     float* stash;              // or nullptr
     long long nbatches;        // ceil(N / (32 * waves per workgroup))
+    int waves;                 // waves per workgroup of the chosen build (4 or 8)
     int coord_table;           // lattice mode: per-axis coordinate tables fit LDS (res0+res1+res2 floats)
 };
 
@@ -129,10 +130,12 @@ __device__ __forceinline__ void lfgc_layer_fwd(const float* __restrict__ s_blk, 
     }
 }
 
-// WAVES = 4: two workgroups per CU, layer blocks staged once ("resident" nets that fit 80 KB of LDS).
-// WAVES = 8: one workgroup per CU, the layer blocks stream through a 2-deep LDS ring by LDS-DMA: the block of
-//            layer t+1 is in flight while layer t computes, one barrier per layer, no exposed staging.
-template <int CH, int MT, int NF, int WAVES, bool STASH>
+// STREAM = false: WAVES = 4, two workgroups per CU, layer blocks staged once ("resident" nets that fit 80 KB of LDS).
+// STREAM = true : one workgroup per CU, the layer blocks stream through a 2-deep LDS ring by LDS-DMA: the block of
+//            layer t+1 is in flight while layer t computes, one barrier per layer, no exposed staging.  WAVES = 8
+//            (256 samples per batch) when there are enough batches to give every CU one, else WAVES = 4 so that a
+//            32 768-sample call (one reference tile / train step) still spreads over all 256 CUs.
+template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
 __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdArgs a) {
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
@@ -147,7 +150,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
     constexpr int BLKMAX = BLK0 > BLK1 ? BLK0 : BLK1;
     constexpr int CHH = CH / 2;          // channels gathered per lane
     constexpr int EPH = EP / 2;          // scalar inputs carried per lane
-    constexpr bool STREAM = (WAVES == 8);
     constexpr int NT = WAVES * 64;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -373,9 +375,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
 
 // Host-side launcher for one (CH, MT) pair: picks the resident (4-wave) or streamed (8-wave) build and the
 // stash / no-stash build.
-template <int CH, int MT, int NF, int WAVES, bool STASH>
+template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
 static int lfgc_launch_fwd_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
-    auto kern = lfgc_fwd_kernel<CH, MT, NF, WAVES, STASH>;
+    auto kern = lfgc_fwd_kernel<CH, MT, NF, WAVES, STREAM, STASH>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -389,9 +391,13 @@ static int lfgc_launch_fwd_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hi
 template <int CH, int MT, int NF>
 static int lfgc_launch_fwd(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
     if (a.resident) {
-        return a.stash ? lfgc_launch_fwd_one<CH, MT, NF, 4, true>(a, lds_bytes, grid, stream)
-                       : lfgc_launch_fwd_one<CH, MT, NF, 4, false>(a, lds_bytes, grid, stream);
+        return a.stash ? lfgc_launch_fwd_one<CH, MT, NF, 4, false, true>(a, lds_bytes, grid, stream)
+                       : lfgc_launch_fwd_one<CH, MT, NF, 4, false, false>(a, lds_bytes, grid, stream);
     }
-    return a.stash ? lfgc_launch_fwd_one<CH, MT, NF, 8, true>(a, lds_bytes, grid, stream)
-                   : lfgc_launch_fwd_one<CH, MT, NF, 8, false>(a, lds_bytes, grid, stream);
+    if (a.waves == 8) {
+        return a.stash ? lfgc_launch_fwd_one<CH, MT, NF, 8, true, true>(a, lds_bytes, grid, stream)
+                       : lfgc_launch_fwd_one<CH, MT, NF, 8, true, false>(a, lds_bytes, grid, stream);
+    }
+    return a.stash ? lfgc_launch_fwd_one<CH, MT, NF, 4, true, true>(a, lds_bytes, grid, stream)
+                   : lfgc_launch_fwd_one<CH, MT, NF, 4, true, false>(a, lds_bytes, grid, stream);
 }

@@ -23,11 +23,18 @@ struct IdwtArgs {
 // Synthesis: out_full[o] = sum_{s,t} in[s][i] F_s[t], o = 2 i + t per axis.  Thread = cell jj in [0,d] per axis:
 // it produces the 2x2x2 outputs o = 2 jj + p from the cells i = jj - e (e in {0,1}) with taps t = p + 2 e.
 __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
-    const float* __restrict__ filt = a.filt;
+    // filter bank re-laid [tap][band] in LDS: the 8 bands of one tap are two broadcast ds_read_b128
+    // (left in global memory hipcc fetches every tap with a per-lane vector load: 512 extra loads per thread)
+    __shared__ __attribute__((aligned(16))) float s_f[512];
+    for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
+    __syncthreads();
     const int n0 = a.d0 + 1, n1 = a.d1 + 1, n2 = a.d2 + 1;
     const long long total = (long long)a.C * n0 * n1 * n2;
     const long long dvol = (long long)a.d0 * a.d1 * a.d2;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    // one cell per thread, no grid-stride loop: a loop makes the LDS filter reads loop-invariant and hipcc then
+    // hoists all 512 taps into VGPRs (256 VGPRs + scratch, occupancy 1)
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < total) {
         const int jx = (int)(idx % n2);
         long long r = idx / n2;
         const int jy = (int)(r % n1); r /= n1;
@@ -57,8 +64,12 @@ __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int tap = ((pz + 2 * (e >> 2)) * 4 + (py + 2 * ((e >> 1) & 1))) * 4 + (px + 2 * (e & 1));
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc = __builtin_fmaf(v[e][s], filt[s * 64 + tap], acc);
+                const f32x4 f0 = *reinterpret_cast<const f32x4*>(s_f + tap * 8);
+                const f32x4 f1 = *reinterpret_cast<const f32x4*>(s_f + tap * 8 + 4);
+                acc = __builtin_fmaf(v[e][0], f0.x, acc); acc = __builtin_fmaf(v[e][1], f0.y, acc);
+                acc = __builtin_fmaf(v[e][2], f0.z, acc); acc = __builtin_fmaf(v[e][3], f0.w, acc);
+                acc = __builtin_fmaf(v[e][4], f1.x, acc); acc = __builtin_fmaf(v[e][5], f1.y, acc);
+                acc = __builtin_fmaf(v[e][6], f1.z, acc); acc = __builtin_fmaf(v[e][7], f1.w, acc);
             }
             const int oz = 2 * jz + pz - a.o0, oy = 2 * jy + py - a.o1, ox = 2 * jx + px - a.o2;
             if (oz >= 0 && oz < a.t0 && oy >= 0 && oy < a.t1 && ox >= 0 && ox < a.t2)
@@ -79,11 +90,14 @@ struct AnalysisArgs {
 };
 
 __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
-    const float* __restrict__ filt = a.filt;
+    __shared__ __attribute__((aligned(16))) float s_f[512];      // [tap][band], see idwt_level_kernel
+    for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
+    __syncthreads();
     const long long dvol = (long long)a.d0 * a.d1 * a.d2;
     const long long nvol = (long long)a.n0 * a.n1 * a.n2;
     const long long total = (long long)a.C * dvol;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one cell per thread (see idwt_level_kernel)
+    if (idx < total) {
         const int ix = (int)(idx % a.d2);
         long long r = idx / a.d2;
         const int iy = (int)(r % a.d1); r /= a.d1;
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
         float acc[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = 0.0f;
-#pragma unroll
+#pragma unroll 1                      // a rolled z-tap loop keeps the live filter taps to one 16-tap plane
         for (int tz = 0; tz < 4; ++tz) {
             const int uz = 2 * iz + tz - a.lo0;
             const bool okz = uz >= 0 && uz < a.n0;
@@ -108,8 +122,12 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
             }
 #pragma unroll
             for (int tyx = 0; tyx < 16; ++tyx) {
-#pragma unroll
-                for (int s = 0; s < 8; ++s) acc[s] = __builtin_fmaf(v[tyx], filt[s * 64 + tz * 16 + tyx], acc[s]);
+                const f32x4 f0 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8);
+                const f32x4 f1 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8 + 4);
+                acc[0] = __builtin_fmaf(v[tyx], f0.x, acc[0]); acc[1] = __builtin_fmaf(v[tyx], f0.y, acc[1]);
+                acc[2] = __builtin_fmaf(v[tyx], f0.z, acc[2]); acc[3] = __builtin_fmaf(v[tyx], f0.w, acc[3]);
+                acc[4] = __builtin_fmaf(v[tyx], f1.x, acc[4]); acc[5] = __builtin_fmaf(v[tyx], f1.y, acc[5]);
+                acc[6] = __builtin_fmaf(v[tyx], f1.z, acc[6]); acc[7] = __builtin_fmaf(v[tyx], f1.w, acc[7]);
             }
         }
         const long long sp_out = ((long long)iz * a.d1 + iy) * a.d2 + ix;
@@ -166,11 +184,9 @@ __global__ __launch_bounds__(256) void last_to_first_kernel(const float* __restr
     }
 }
 
-inline int grid_for(long long total, int block = 256, int cap = 256 * 64) {
+inline unsigned grid_for(long long total, int block = 256) {
     long long g = (total + block - 1) / block;
-    if (g < 1) g = 1;
-    if (g > cap) g = cap;
-    return (int)g;
+    return (unsigned)(g < 1 ? 1 : g);
 }
 
 inline int check_level(const void* a, const void* b, const void* c, const void* d, int C, int d0, int d1, int d2,
