@@ -41,6 +41,8 @@ WORKLOADS = {
     # name: (volume edge, grid channels C, grid edge G, hidden H, layers L)
     'headline': dict(vol=256, C=32, G=64, H=128, L=4,
                      desc='256^3 full-volume reconstruction, 64^3x32ch grid (4-level db2), MLP 4x128, fp32'),
+    'cfg5': dict(vol=1024, C=32, G=128, H=128, L=4, levels=3,
+                 desc='1024^3 full-volume reconstruction, 128^3x32ch grid (3-level db2), MLP 4x128, fp32'),
     'cfg2': dict(vol=150, C=16, G=32, H=64, L=4,
                  desc='150^3 full-volume reconstruction, 32^3x16ch grid (3-level db2), MLP 4x64, fp32'),
 }
@@ -55,7 +57,7 @@ def build_model(w, seed, device):
     rng = np.random.Generator(np.random.PCG64(seed))
     grid = torch.from_numpy(rng.random((w['C'], w['G'], w['G'], w['G']), dtype=np.float32)).to(device)
     model = Feature_Grid_Model(FourierEmbedding(2, 3), grid, None, WaveletFilter3d('db2').to(device),
-                               hidden_channel=w['H'], num_layer=w['L'])
+                               hidden_channel=w['H'], num_layer=w['L'], num_levels=w.get('levels'))
     with torch.no_grad():
         for lin in list(model.net_layers) + [model.final_layer]:
             bound = 1.0 / math.sqrt(lin.in_features)

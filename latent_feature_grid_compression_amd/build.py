@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG_DIR, 'csrc')
 OBJ_DIR = os.path.join(CSRC, 'build')
 LIB_PATH = os.path.join(PKG_DIR, 'liblfgc.so')
 ARCH = 'gfx950'
-FLAGS = ['--offload-arch=' + ARCH, '-O3', '-ffp-contract=off', '-fPIC', '-std=c++17', '-Wno-unused-result']
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-ffp-contract=off', '-fno-slp-vectorize', '-fPIC', '-std=c++17', '-Wno-unused-result']
 
 
 def _hipcc() -> str:
@@ -77,11 +77,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
-def build_variant(out_path: str, defines, verbose: bool = True) -> str:
+def build_variant(out_path: str, defines, verbose: bool = True, flags=()) -> str:
     """Diagnostics: build a separate library with extra -D flags (e.g. LFGC_ABLATE=1) next to the product one."""
     obj_dir = out_path + '.objs'
     os.makedirs(obj_dir, exist_ok=True)
-    extra = ['-D' + d for d in defines]
+    extra = ['-D' + d for d in defines] + list(flags)
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(lambda s_: _compile(s_, obj_dir, extra), sources()))
     r = subprocess.run([_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', out_path] + objs,

@@ -14,15 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'tools', 'microbench', 'ablate')
 MASKS = {'full': 0, 'no_gather': 1, 'no_activation': 2, 'no_gather_no_activation': 3, 'no_mfma': 4}
+FLAG_VARIANTS = {'full_noslp': ['-fno-slp-vectorize']}
 
 if sys.argv[1] == 'build':
     from latent_feature_grid_compression_amd.build import build_variant
     os.makedirs(OUT, exist_ok=True)
     for name, mask in MASKS.items():
         build_variant(os.path.join(OUT, 'liblfgc_%s.so' % name), ['LFGC_ABLATE=%d' % mask])
+    for name, flags in FLAG_VARIANTS.items():
+        build_variant(os.path.join(OUT, 'liblfgc_%s.so' % name), ['LFGC_ABLATE=0'], flags=flags)
 elif sys.argv[1] == 'run':
     res = {}
-    for name in MASKS:
+    for name in list(MASKS) + list(FLAG_VARIANTS):
         env = dict(os.environ, LFGC_LIB_PATH=os.path.join(OUT, 'liblfgc_%s.so' % name))
         r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '5', '--warmup', '2',
                             '--no-cpu-baseline', '--no-check'], env=env, capture_output=True, text=True)
