@@ -123,6 +123,16 @@ typedef struct lfgc_positions {
     int32_t tile;            /* reference: 32 */
 } lfgc_positions;
 
+/* Arithmetic of the layer GEMMs inside lfgc_forward_f32 (inputs, outputs, accumulation and every other operation
+ * are fp32 in both):
+ *   LFGC_PRECISION_F32    v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain per output;
+ *   LFGC_PRECISION_F16X2  every fp32 operand carried as an f16 pair hi + lo (22-24 significant bits), three
+ *                         v_mfma_f32_32x32x16_f16 per product block with fp32 accumulation: same error level as the
+ *                         fp32 build against the reference (fp32 summation order dominates), ~3x the throughput.
+ *                         Needs |activations| < 65504. */
+#define LFGC_PRECISION_F32 0
+#define LFGC_PRECISION_F16X2 1
+
 /* forward().  Replaces model/Feature_Grid_Model.py:62-78 (everything after decode_volume):
  * F.grid_sample(bilinear, align_corners=False, zeros) of the dense grid, Embedder.embed
  * (model/Feature_Embedding.py:14-16), torch.cat, L x (Linear + SnakeAlt), final Linear, optional
@@ -134,7 +144,7 @@ typedef struct lfgc_positions {
  *             pre-activation are saved for lfgc_backward_f32 (private layout). */
 int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
                      const float* grid_cl, int D, int H, int W,
-                     const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream);
+                     const float* packed, int precision, int clamp, float* out, float* stash, lfgc_stream_t stream);
 
 /* Backward of lfgc_forward_f32 (what autograd derives for model/Feature_Grid_Model.py:62-75;
  * triggered at training/training.py:137).  positions->pos must be non-NULL.

@@ -9,6 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LFGC_LIB_PATH') or os.path.join(PKG_DIR, 'liblfgc.so')   # override: diagnostics builds only
 LFGC_MAX_LAYERS = 8
+PRECISION = {'fp32': 0, 'f16x2': 1}
 
 
 class LfgcError(RuntimeError):
@@ -41,7 +42,7 @@ SIGNATURES = {
     'lfgc_stash_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'lfgc_pack_mlp_f32': (c_int, [POINTER(MlpDesc), _PP, _PP, c_void_p, c_void_p]),
     'lfgc_forward_f32': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
-                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'lfgc_backward_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'lfgc_backward_f32': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, _PP, _PP, c_void_p,

@@ -5,6 +5,10 @@ int lfgc_fwd_dispatch_ch8(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid,
 int lfgc_fwd_dispatch_ch16(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
 int lfgc_fwd_dispatch_ch24(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
 int lfgc_fwd_dispatch_ch32(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+int lfgc_fwd16_dispatch_ch8(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+int lfgc_fwd16_dispatch_ch16(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+int lfgc_fwd16_dispatch_ch24(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
+int lfgc_fwd16_dispatch_ch32(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
 
 namespace {
 int g_num_cus = 0;
@@ -48,10 +52,12 @@ int lfgc_fill_positions(const lfgc_positions* ps, LfgcFwdArgs* a, long long* n_o
 
 extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
                                 const float* grid_cl, int D, int H, int W,
-                                const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream) {
+                                const float* packed, int precision, int clamp, float* out, float* stash,
+                                lfgc_stream_t stream) {
     if (!desc || !positions || !grid_cl || !packed || !out) return LFGC_E_NULL;
     if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
     if (D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
+    if (precision != LFGC_PRECISION_F32 && precision != LFGC_PRECISION_F16X2) return LFGC_E_UNSUPPORTED;
     if ((((uintptr_t)grid_cl) | ((uintptr_t)packed)) & 15) return LFGC_E_ALIGN;
     const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
     LfgcFwdArgs a;
@@ -65,10 +71,12 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     // LDS: [Wf | bf] + every layer block (resident: 4-wave workgroups, two per CU) or a 2-deep ring of the
     // largest block (streamed: 8-wave workgroups, one per CU).  The stash is laid out per 32-sample tile in
     // whole 128-sample groups either way (lfgc_stash_bytes), so both builds write the same format.
-    const int all_blocks = p.off_final;
-    const int max_block = p.blk0 > p.blk1 ? p.blk0 : p.blk1;
-    a.resident = ((p.HP + 4 + all_blocks) * 4 <= 80 * 1024) ? 1 : 0;
-    int lds_bytes = (p.HP + 4 + (a.resident ? all_blocks : 2 * max_block)) * 4;
+    const bool h16 = precision == LFGC_PRECISION_F16X2;
+    const int all_blocks = h16 ? p.blkh0 + (p.L - 1) * p.blkh1 : p.off_final;
+    const int max_block = h16 ? (p.blkh0 > p.blkh1 ? p.blkh0 : p.blkh1) : (p.blk0 > p.blk1 ? p.blk0 : p.blk1);
+    const int fixed = p.HP + 4 + (h16 ? 16 : 0);        // [Wf | bf] (+ per-layer scales)
+    a.resident = ((fixed + all_blocks) * 4 <= 80 * 1024) ? 1 : 0;
+    int lds_bytes = (fixed + (a.resident ? all_blocks : 2 * max_block)) * 4;
     a.coord_table = 0;
     if (!a.pos) {                                       // per-axis coordinate tables behind the weight region
         const long long tbl = 4LL * ((long long)a.res0 + a.res1 + a.res2);
@@ -82,6 +90,15 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     long long grid = (a.resident ? 2LL : 1LL) * num_cus();
     if (grid > a.nbatches) grid = a.nbatches;
     hipStream_t st = (hipStream_t)stream;
+    if (h16) {
+        switch (p.CH) {
+            case 8: return lfgc_fwd16_dispatch_ch8(p.MT, a, lds_bytes, (int)grid, st);
+            case 16: return lfgc_fwd16_dispatch_ch16(p.MT, a, lds_bytes, (int)grid, st);
+            case 24: return lfgc_fwd16_dispatch_ch24(p.MT, a, lds_bytes, (int)grid, st);
+            case 32: return lfgc_fwd16_dispatch_ch32(p.MT, a, lds_bytes, (int)grid, st);
+            default: return LFGC_E_UNSUPPORTED;
+        }
+    }
     switch (p.CH) {
         case 8: return lfgc_fwd_dispatch_ch8(p.MT, a, lds_bytes, (int)grid, st);
         case 16: return lfgc_fwd_dispatch_ch16(p.MT, a, lds_bytes, (int)grid, st);

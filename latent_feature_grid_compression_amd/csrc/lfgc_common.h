@@ -34,6 +34,10 @@ struct LfgcPlan {
     int off_t;               // float offset of the transposed part
     int total_floats;
     int stash_tile_floats;   // floats saved per 32-sample tile: 64 * (KS0 + L*16*MT)
+    // f16-split forward section (lfgc_forward16.h): per-layer power-of-two scales, then layer blocks whose rows
+    // hold, per 16-column k-step, [lane half 0: 8 hi halfs | 8 lo halfs][lane half 1: 8 hi | 8 lo] (64 B), i.e.
+    // 4 bytes per weight like the fp32 blocks, same +16 B row padding, followed by the scaled fp32 bias.
+    int K0P16, SH0, SH1, blkh0, blkh1, off_h, off_hblk;
 };
 
 __host__ __device__ inline int lfgc_roundup(int v, int m) { return (v + m - 1) / m * m; }
@@ -61,7 +65,14 @@ __host__ __device__ inline LfgcPlan lfgc_make_plan(int C, int H, int L, int NF) 
     p.tblk0 = p.K0R * p.ST;
     p.tblk1 = p.HP * p.ST;
     p.off_t = p.fwd_floats;
-    p.total_floats = p.off_t + p.tblk0 + (L - 1) * p.tblk1;
+    p.K0P16 = lfgc_roundup(p.K0P, 16);
+    p.SH0 = p.K0P16 + 4;
+    p.SH1 = p.HP + 4;
+    p.blkh0 = p.HP * p.SH0 + p.HP;
+    p.blkh1 = p.HP * p.SH1 + p.HP;
+    p.off_h = p.off_t + p.tblk0 + (L - 1) * p.tblk1;         // 16 floats: scale[8] | 1/scale[8]
+    p.off_hblk = p.off_h + 16;
+    p.total_floats = p.off_hblk + p.blkh0 + (L - 1) * p.blkh1;
     p.stash_tile_floats = 64 * (p.KS0 + L * 16 * p.MT);
     return p;
 }
@@ -80,6 +91,27 @@ __host__ __device__ inline int lfgc_layer0_src_col(const LfgcPlan& p, int cl) {
     }
     const int e = hh * (p.EP / 2) + (s - p.CH / 2);
     return e < p.E ? e : -1;
+}
+
+// f16-split blocks: original nn.Linear column held by (k-step b, lane half hp, element jj) of layer l, or -1.
+// Hidden layers: the k order of a 32x32x16 MFMA step follows the accumulator rows a lane holds in registers
+// 8s..8s+7 of tile m (b = 2m + s): column 32m + 16s + (jj&3) + 8(jj>>2) + 4hp.  Layer 0: lane half hp feeds its
+// own input list X[8b + jj] = [CH/2 grid channels | EP/2 scalars | zero pad]  (lfgc_sample_inputs).
+__host__ __device__ inline int lfgc_h16_src_col(const LfgcPlan& p, int l, int b, int hp, int jj) {
+    if (l > 0) {
+        const int c = 16 * b + (jj & 3) + 8 * (jj >> 2) + 4 * hp;
+        return c < p.H ? c : -1;
+    }
+    const int idx = 8 * b + jj;
+    if (idx < p.CH / 2) {
+        const int ch = hp * (p.CH / 2) + idx;
+        return ch < p.C ? p.E + ch : -1;
+    }
+    if (idx < p.CH / 2 + p.EP / 2) {
+        const int e = hp * (p.EP / 2) + (idx - p.CH / 2);
+        return e < p.E ? e : -1;
+    }
+    return -1;
 }
 
 // ------------------------------------------------------------------------------------------------

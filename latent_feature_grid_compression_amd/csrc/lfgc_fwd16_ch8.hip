@@ -1,0 +1,10 @@
+// f16-split forward-kernel instantiations for grid channel stride 8
+#include "lfgc_forward16.h"
+int lfgc_fwd16_dispatch_ch8(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
+    switch (MT) {
+        case 1: return lfgc_launch_fwd16<8, 1, 2>(a, lds_bytes, grid, stream);
+        case 2: return lfgc_launch_fwd16<8, 2, 2>(a, lds_bytes, grid, stream);
+        case 4: return lfgc_launch_fwd16<8, 4, 2>(a, lds_bytes, grid, stream);
+        default: return LFGC_E_UNSUPPORTED;
+    }
+}

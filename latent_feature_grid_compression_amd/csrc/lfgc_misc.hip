@@ -119,6 +119,30 @@ struct PackArgs {
     LfgcPlan plan;
 };
 
+// Per-layer power-of-two scale for the f16-split blocks: 2^S with max|W| * 2^S in [2^13, 2^14), so that the hi
+// halves stay far below the f16 maximum and the lo halves (<= 2^-11 of the hi) stay normal for every weight within
+// 2^-16 of the largest.  One block per hidden layer.
+__global__ __launch_bounds__(256) void pack_scale_kernel(const PackArgs a) {
+    const LfgcPlan& p = a.plan;
+    const int l = blockIdx.x;
+    const int n = (l == 0) ? p.H * (p.E + p.C) : p.H * p.H;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(a.w[l][i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        int e = 0;
+        if (m > 0.0f && m < INFINITY) { (void)frexpf(m, &e); e = 14 - e; }    // m = f * 2^e', f in [0.5,1) -> m * 2^(14-e') in [2^13, 2^14)
+        if (e > 60) e = 60;
+        if (e < -60) e = -60;
+        a.packed[p.off_h + l] = ldexpf(1.0f, e);
+        a.packed[p.off_h + 8 + l] = ldexpf(1.0f, -e);
+    }
+}
+
 // Re-lay nn.Linear parameters into the blob described in lfgc_common.h.
 __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
     const LfgcPlan& p = a.plan;
@@ -157,12 +181,46 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
                 const int src = lfgc_layer0_src_col(p, cl);
                 if (src >= 0) v = a.w[0][ho * K0 + src];
             }
-        } else {                                              // hidden layers transposed: [k_in][h_out]
+        } else if (idx < p.off_h) {                           // hidden layers transposed: [k_in][h_out]
             const int o = idx - p.off_t - p.tblk0;
             const int l = 1 + o / p.tblk1;
             const int oo = o % p.tblk1;
             const int ki = oo / p.ST, ho = oo % p.ST;
             if (ki < p.H && ho < p.H) v = a.w[l][ho * p.H + ki];
+        } else if (idx < p.off_hblk) {
+            continue;                                         // scales: written by pack_scale_kernel
+        } else {                                              // f16-split blocks (hi | lo halves, scaled)
+            const int o = idx - p.off_hblk;
+            const int l = o < p.blkh0 ? 0 : 1 + (o - p.blkh0) / p.blkh1;
+            const int oo = o < p.blkh0 ? o : (o - p.blkh0) % p.blkh1;
+            const int SH = l == 0 ? p.SH0 : p.SH1;
+            const int K = l == 0 ? p.K0P16 : p.HP;
+            const int Kin = l == 0 ? (p.E + p.C) : p.H;
+            const float scale = a.packed[p.off_h + l];
+            if (oo < p.HP * SH) {
+                const int row = oo / SH, q = oo % SH;
+                unsigned bits = 0;
+                if (row < p.H && q < K) {
+                    const int b = q >> 4, t = q & 15;
+                    const int hp = t >> 3, part = (t >> 2) & 1, pair = t & 3;
+                    unsigned short hv[2] = {0, 0};
+                    for (int u = 0; u < 2; ++u) {
+                        const int src = lfgc_h16_src_col(p, l, b, hp, 2 * pair + u);
+                        if (src >= 0) {
+                            const float w = a.w[l][row * Kin + src] * scale;
+                            const _Float16 hi = (_Float16)w;
+                            const _Float16 lo = (_Float16)(w - (float)hi);
+                            const _Float16 x = part ? lo : hi;
+                            hv[u] = *reinterpret_cast<const unsigned short*>(&x);
+                        }
+                    }
+                    bits = (unsigned)hv[0] | ((unsigned)hv[1] << 16);
+                }
+                v = __uint_as_float(bits);
+            } else {
+                const int r = oo - p.HP * SH;
+                if (r < p.H) v = a.b[l][r] * scale;
+            }
         }
         a.packed[idx] = v;
     }
@@ -234,6 +292,8 @@ extern "C" int lfgc_pack_mlp_f32(const lfgc_mlp_desc* d, const float* const* wei
         a.b[l] = biases[l];
     }
     a.packed = packed;
+    hipLaunchKernelGGL(pack_scale_kernel, dim3(a.plan.L), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
     const int g = (a.plan.total_floats + 255) / 256;
     hipLaunchKernelGGL(pack_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, (hipStream_t)stream, a);
     LFGC_HIP_CHECK_LAUNCH();

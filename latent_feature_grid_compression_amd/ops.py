@@ -183,7 +183,8 @@ def _positions_struct(pos: Optional[torch.Tensor], lattice=None) -> Tuple[Positi
 
 
 def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos: Optional[torch.Tensor] = None,
-                lattice=None, clamp: bool = False, want_stash: bool = False, out: Optional[torch.Tensor] = None):
+                lattice=None, clamp: bool = False, want_stash: bool = False, out: Optional[torch.Tensor] = None,
+                precision: str = 'f16x2'):
     """lfgc_forward_f32.  pos (N,3) or lattice=(res, x_begin, x_end, tile).  Returns (y (N,), stash or None)."""
     lib = _lib.load()
     _require_hip(grid_cl, packed, pos)
@@ -201,8 +202,8 @@ def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos:
     if want_stash:
         stash = torch.empty(int(lib.lfgc_stash_bytes(ctypes.byref(desc), n)) // 4, dtype=torch.float32, device=grid_cl.device)
     check(lib.lfgc_forward_f32(ctypes.byref(desc), ctypes.byref(ps), grid_cl.data_ptr(), D, H, W, packed.data_ptr(),
-                               int(clamp), out.data_ptr(), stash.data_ptr() if stash is not None else None,
-                               _stream(grid_cl)), 'lfgc_forward_f32')
+                               _lib.PRECISION[precision], int(clamp), out.data_ptr(),
+                               stash.data_ptr() if stash is not None else None, _stream(grid_cl)), 'lfgc_forward_f32')
     return out, stash
 
 
@@ -232,10 +233,11 @@ class SampleDecodeFn(torch.autograd.Function):
     """model/Feature_Grid_Model.py:62-75 as one autograd node (HIP forward + HIP backward)."""
 
     @staticmethod
-    def forward(ctx, desc, pos, grid_cl, packed, n_layers, *params):
+    def forward(ctx, desc, pos, grid_cl, packed, n_layers, precision, *params):
         weights, biases = params[:n_layers + 1], params[n_layers + 1:]
         need_grad = any(t.requires_grad for t in (pos, grid_cl) + tuple(params))
-        y, stash = forward_raw(desc, grid_cl.detach(), packed, pos=pos.detach(), clamp=False, want_stash=need_grad)
+        y, stash = forward_raw(desc, grid_cl.detach(), packed, pos=pos.detach(), clamp=False, want_stash=need_grad,
+                               precision=precision)
         if need_grad:
             ctx.desc = desc
             ctx.n_layers = n_layers
@@ -251,7 +253,7 @@ class SampleDecodeFn(torch.autograd.Function):
         weights, biases = params[:L + 1], params[L + 1:]
         d_grid, d_w, d_b, d_pos = backward_raw(ctx.desc, grid_cl, packed, pos, stash, d_y.reshape(-1), weights, biases,
                                                ctx.need_d_pos)
-        return (None, d_pos, d_grid, None, None) + tuple(d_w) + tuple(d_b)
+        return (None, d_pos, d_grid, None, None, None) + tuple(d_w) + tuple(d_b)
 
 
 # ---- ground truth / statistics -------------------------------------------------------------------------

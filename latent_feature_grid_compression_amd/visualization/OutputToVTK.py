@@ -62,7 +62,8 @@ def field_from_net_fused(dataset, net, x_begin: int = 0, x_end: Optional[int] = 
         grid_cl = net._decoded_channel_last()
         flat = None if out is None else out.view(-1)
         y, _ = ops.forward_raw(net._descriptor(), grid_cl, net._packed(), pos=None,
-                               lattice=(res, x_begin, x_end, tiled_res), clamp=True, out=flat)
+                               lattice=(res, x_begin, x_end, tiled_res), clamp=True, out=flat,
+                               precision=getattr(net, 'precision', 'f16x2'))
     return y.view(x_end - x_begin, res[1], res[2])
 
 

@@ -55,7 +55,8 @@ def test_pure_host_entry_points(built_lib):
     HP, K0P, K0R, L = 128, 48, 64, 4
     fwd = HP * (K0P + 4) + HP + (L - 1) * (HP * (HP + 4) + HP) + HP + 4
     tr = K0R * (HP + 4) + (L - 1) * HP * (HP + 4)
-    assert lib.lfgc_packed_bytes(ctypes.byref(ok)) == 4 * (fwd + tr)
+    h16 = 16 + HP * (48 + 4) + HP + (L - 1) * (HP * (HP + 4) + HP)        # scales + f16-split blocks (K0P16 = 48)
+    assert lib.lfgc_packed_bytes(ctypes.byref(ok)) == 4 * (fwd + tr + h16)
     # stash: whole workgroup batches of 8 x 32 samples, 64 lanes x (KS0 + L*16*MT) floats per tile
     assert lib.lfgc_stash_bytes(ctypes.byref(ok), 1) == 4 * 8 * 64 * (24 + 4 * 64)
     assert lib.lfgc_stash_bytes(ctypes.byref(ok), 32768) == 4 * 1024 * 64 * (24 + 4 * 64)
@@ -64,7 +65,7 @@ def test_pure_host_entry_points(built_lib):
     assert b'NULL' in lib.lfgc_error_string(-1)
     # NULL / shape errors are reported before anything is launched
     assert lib.lfgc_idwt_level_f32(None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None) == -1
-    assert lib.lfgc_forward_f32(ctypes.byref(ok), None, None, 1, 1, 1, None, 0, None, None, None) == -1
+    assert lib.lfgc_forward_f32(ctypes.byref(ok), None, None, 1, 1, 1, None, 0, 0, None, None, None) == -1
     assert lib.lfgc_gt_interp_f32(None, None, None, None, None, 0, 1, 1, 1, None, None) == -1
 
 
