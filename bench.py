@@ -35,6 +35,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
+F16_MFMA_PEAK_TFLOPS = 2500.0      # same guide, dense BF16/F16 MFMA
+# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r1/*pmc_hbm*.json):
+# 2 x FETCH_SIZE (gfx950 correction for 16-B/lane reads) + WRITE_SIZE, per (workload, precision); None = not collected
+TRAFFIC_BYTES = {}
 HBM_PEAK_GBS = 8000.0              # same guide, HBM3E spec
 
 WORKLOADS = {
@@ -107,6 +111,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='headline', choices=sorted(WORKLOADS))
+    ap.add_argument('--precision', default='f16x2', choices=['f16x2', 'fp32'],
+                    help="layer-GEMM arithmetic: 'f16x2' (default, f16 hi+lo split on the f16 matrix pipe) or 'fp32' (exact f32 MFMA)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true', help='skip the finite-output check (ablation builds)')
     args = ap.parse_args()
@@ -131,13 +137,14 @@ def main():
 
     w = WORKLOADS[args.workload]
     model = build_model(w, seed=2003, device=device)
+    model.precision = args.precision
     ds = IndexDataset((w['vol'],) * 3, 16, build_index_table=False)
     res = ds.vol_res_touple
     parts = V.slab_partition(res[0], world, 32)
     my_b, my_e = parts[rank]
     my_samples = (my_e - my_b) * res[1] * res[2]
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = []                                   # (start, end, samples) per timed launch of the dominant kernel
     step_state = {'i': -1}
 
     def slab_fn(b, e, out_view):
@@ -145,13 +152,15 @@ def main():
         with torch.no_grad():
             grid_cl = model._decoded_channel_last()
             packed = model._packed()
-            i = step_state['i']
-            if i >= 0:
-                ev[i][0].record()
+            timed = step_state['i'] >= 0
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.forward_raw(model._descriptor(), grid_cl, packed, pos=None, lattice=(res, b, e, 32), clamp=True,
-                            out=out_view.view(-1))
-            if i >= 0:
-                ev[i][1].record()
+                            out=out_view.view(-1), precision=model.precision)
+            if timed:
+                e1.record()
+                ev.append((e0, e1, (e - b) * res[1] * res[2]))
 
     def one_step():
         model._grid_cache = None          # every pass decodes the wavelet-coded grid and re-packs: no cached outputs
@@ -179,7 +188,9 @@ def main():
     elapsed = t.item()
     assert tuple(vol.shape) == tuple(res) and (args.no_check or bool(torch.isfinite(vol).all()))
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if my_samples > 0 else float('nan')
+    kern_total_ms = float(sum(a.elapsed_time(b) for a, b, _ in ev))
+    kern_samples = int(sum(n for _, _, n in ev))
+    kern_ms = kern_total_ms / max(len(ev), 1)
     total_samples = res[0] * res[1] * res[2]
     value = total_samples * args.steps / elapsed / 1e6
 
@@ -187,21 +198,31 @@ def main():
         K0 = 3 + 12 + w['C']
         flop_per_sample = 2 * (K0 * w['H'] + (w['L'] - 1) * w['H'] ** 2 + w['H'])
         bytes_per_sample = 12 + 4 + 8 * w['C'] * 4
-        achieved_tflops = flop_per_sample * my_samples / (kern_ms * 1e-3) / 1e12
-        hbm_alg_gbs = bytes_per_sample * my_samples / (kern_ms * 1e-3) / 1e9
+        achieved_tflops = flop_per_sample * kern_samples / (kern_total_ms * 1e-3) / 1e12
+        hbm_alg_gbs = bytes_per_sample * kern_samples / (kern_total_ms * 1e-3) / 1e9
+        split = model.precision == 'f16x2'
+        # f16x2: every fp32 product block is three f16 MFMAs -> fp32-equivalent ceiling = f16 dense peak / 3
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
         out = {
             'metric': 'Msamples/s (grid-interp+embed+MLP fwd) on 256^3 volume' if args.workload == 'headline'
                       else 'Msamples/s (grid-interp+embed+MLP fwd)',
             'value': value, 'unit': 'Msamples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32 (layer GEMMs as f16 hi+lo split, f32 accumulate)' if model.precision == 'f16x2' else 'f32',
+            'data': 'synthetic',
             'config': {'workload': w['desc'], 'samples_per_step': total_samples, 'tiles': 'x-slabs of 32^3 tiles',
-                       'parallelism': 'tile-slab x%d + one all-gather' % world if world > 1 else 'single GPU',
+                       'parallelism': 'tile-slab x%d, chunked all-gather overlapped with compute' % world if world > 1 else 'single GPU',
                        'step_includes': 'wavelet decode + param pack + fused forward' + (' + RCCL all-gather' if world > 1 else '')},
-            'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved_tflops / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
-                         'kernel': 'lfgc_fwd_kernel', 'kernel_ms': kern_ms, 'samples_per_launch': my_samples,
-                         'flop_per_sample': flop_per_sample,
+            'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved_tflops / peak, 'traffic': TRAFFIC_BYTES.get((args.workload, model.precision)),
+                         'kernel': 'lfgc_fwd16_kernel' if split else 'lfgc_fwd_kernel', 'kernel_ms': kern_ms,
+                         'launches_per_step': len(ev) // max(args.steps, 1),
+                         'samples_per_launch': kern_samples // max(len(ev), 1), 'flop_per_sample': flop_per_sample,
+                         'peak_note': ('fp32-equivalent ceiling of the f16-split GEMM: 2500 TFLOP/s dense f16 MFMA / 3 '
+                                       'MFMAs per fp32 product block; executed f16 MFMA rate = 3 x achieved'
+                                       if split else 'dense f32-input MFMA (v_mfma_f32_32x32x2_f32)'),
+                         'vs_fp32_mfma_peak': achieved_tflops / FP32_MFMA_PEAK_TFLOPS,
                          'hbm_algorithmic': {'bytes_per_sample': bytes_per_sample, 'achieved_GBs': hbm_alg_gbs,
                                              'peak_GBs': HBM_PEAK_GBS, 'frac': hbm_alg_gbs / HBM_PEAK_GBS}},
         }

@@ -53,9 +53,13 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
         for (int ks = 0; ks < KS16; ++ks) {
             const h16x8 whi = *reinterpret_cast<const h16x8*>(arow + 16 * ks);
             const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
+#if LFGC_ABLATE & 4
+            acc[ks & 15] += (float)whi[0] * (float)Bhi[ks][0] + (float)wlo[1] * (float)Blo[ks][1];
+#else
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, Bhi[ks], acc, 0, 0, 0);      // small terms first
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Blo[ks], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Bhi[ks], acc, 0, 0, 0);
+#endif
         }
         float av[16];
 #pragma unroll
@@ -70,8 +74,14 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
 #pragma unroll
         for (int r = 0; r < 16; r += 2) amax = lfgc_absmax3(amax, av[r], av[r + 1]);
         float hv[16];
+#if LFGC_ABLATE & 2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = 0.5f * av[r];
+        amax = 0.0f;
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) hv[r] = lfgc_snake_t<false>(av[r]);
+#endif
         if (__builtin_expect(__any(amax > LFGC_TRIG_FAST_MAX), 0)) {       // wave-uniform; a diverged model only
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[r] = lfgc_snake_t<true>(av[r]);
@@ -84,8 +94,13 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
                 ydot = __builtin_fmaf(w4.z, hv[4 * q + 2], ydot); ydot = __builtin_fmaf(w4.w, hv[4 * q + 3], ydot);
             }
         } else {
+#if LFGC_ABLATE & 8
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { Ohi[2 * m][t] = (_Float16)hv[t]; Olo[2 * m][t] = (_Float16)0; Ohi[2 * m + 1][t] = (_Float16)hv[8 + t]; Olo[2 * m + 1][t] = (_Float16)0; }
+#else
             lfgc_split8(hv, Ohi[2 * m], Olo[2 * m]);
             lfgc_split8(hv + 8, Ohi[2 * m + 1], Olo[2 * m + 1]);
+#endif
         }
     }
 }

@@ -125,9 +125,13 @@ def slab_partition(res_x: int, world_size: int, tiled_res: int = 32) -> List[Tup
 
 def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=None,
                                slab_fn: Optional[Callable[[int, int, torch.Tensor], None]] = None,
-                               device: Optional[torch.device] = None) -> torch.Tensor:
-    """Every rank evaluates its x-slab into a padded (max_slab_x, Y, Z) buffer, ONE all_gather_into_tensor
-    assembles (world, max_slab_x, Y, Z), the padding is trimmed.  Returns the full (X,Y,Z) volume on every rank.
+                               device: Optional[torch.device] = None, chunks: Optional[int] = None) -> torch.Tensor:
+    """Every rank evaluates its x-slab of tiles and the slabs are assembled with all-gathers; returns the full
+    (X,Y,Z) volume on every rank.
+
+    The slab is cut into ``chunks`` pieces of whole tile planes (default: one per tile plane, at most 4); each piece is
+    gathered with its own ``all_gather_into_tensor`` issued asynchronously right after the piece's kernel launch, so
+    the collective of piece c (RCCL's stream, xGMI) runs under the compute of piece c+1.  ``chunks=1`` = one gather.
 
     ``slab_fn(x_begin, x_end, out_view)`` fills ``out_view`` ((x_end-x_begin, Y, Z)); default = the fused HIP
     forward of ``net``.  (The CPU/gloo tests inject a stub here: the HIP path itself has no CPU form.)"""
@@ -143,17 +147,34 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
     if slab_fn is None:
         def slab_fn(b, e, out_view):
             field_from_net_fused(dataset, net, b, e, tiled_res, out=out_view)
-    gathered = torch.empty((world, max_x, res[1], res[2]), dtype=torch.float32, device=device)
     b, e = parts[rank]
     if world == 1:
+        out = torch.empty(res, dtype=torch.float32, device=device)
         if e > b:
-            slab_fn(b, e, gathered[0, :e - b])
-        return gathered[0, :res[0]]
-    mine = torch.zeros((max_x, res[1], res[2]), dtype=torch.float32, device=device)
-    if e > b:
-        slab_fn(b, e, mine[:e - b])
-    # concatenated (world * max_x, Y, Z) form: accepted by both RCCL and gloo
-    dist.all_gather_into_tensor(gathered.view(world * max_x, res[1], res[2]), mine, group=group)
-    if all(e_ - b_ == max_x for b_, e_ in parts):
-        return gathered.view(world * max_x, res[1], res[2])[:res[0]]
-    return torch.cat([gathered[r, :e_ - b_] for r, (b_, e_) in enumerate(parts)], 0)
+            slab_fn(b, e, out[b:e])
+        return out
+    # piece boundaries relative to the slab start, on tile planes, identical on every rank (from max_x)
+    planes = (max_x + tiled_res - 1) // tiled_res
+    n_chunks = max(1, min(planes, 4 if chunks is None else int(chunks)))
+    cuts = [min(((c * planes) // n_chunks) * tiled_res, max_x) for c in range(n_chunks + 1)]
+    cuts[-1] = max_x
+    bufs, works = [], []
+    for c in range(n_chunks):
+        lo, hi = cuts[c], cuts[c + 1]
+        mine = torch.zeros((hi - lo, res[1], res[2]), dtype=torch.float32, device=device)
+        xb, xe = min(b + lo, e), min(b + hi, e)
+        if xe > xb:
+            slab_fn(xb, xe, mine[:xe - xb])
+        gathered = torch.empty((world * (hi - lo), res[1], res[2]), dtype=torch.float32, device=device)
+        works.append(dist.all_gather_into_tensor(gathered, mine, group=group, async_op=True))
+        bufs.append((gathered, hi - lo))
+    for w in works:
+        w.wait()
+    pieces = []
+    for r, (rb, re_) in enumerate(parts):
+        for c in range(n_chunks):
+            gathered, span = bufs[c]
+            take = max(0, min(re_ - rb - cuts[c], span))
+            if take > 0:
+                pieces.append(gathered[r * span:r * span + take])
+    return torch.cat(pieces, 0)

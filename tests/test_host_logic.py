@@ -168,7 +168,7 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, res, out_dir):
+def _gloo_worker(rank, world, port, res, out_dir, chunks=None):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -185,16 +185,17 @@ def _gloo_worker(rank, world, port, res, out_dir):
         z = torch.arange(res[2], dtype=torch.float32).view(1, 1, -1)
         out_view.copy_(x * 10000 + y * 100 + z)
 
-    vol = reconstruct_volume_sharded(ds, None, 32, slab_fn=slab_fn, device=torch.device('cpu'))
+    vol = reconstruct_volume_sharded(ds, None, 32, slab_fn=slab_fn, device=torch.device('cpu'), chunks=chunks)
     torch.save({'vol': vol.clone(), 'calls': calls}, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('res,world', [((70, 9, 11), 2), ((33, 5, 4), 2), ((64, 6, 6), 2)])
-def test_sharded_reconstruction_world2_gloo(tmp_path, res, world):
+@pytest.mark.parametrize('res,world,chunks', [((70, 9, 11), 2, None), ((33, 5, 4), 2, None), ((64, 6, 6), 2, 1),
+                                              ((200, 4, 5), 2, 3), ((255, 3, 3), 3, None)])
+def test_sharded_reconstruction_gloo(tmp_path, res, world, chunks):
     port = _free_port()
-    mp.spawn(_gloo_worker, args=(world, port, res, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_gloo_worker, args=(world, port, res, str(tmp_path), chunks), nprocs=world, join=True)
     x = torch.arange(res[0], dtype=torch.float32).view(-1, 1, 1)
     y = torch.arange(res[1], dtype=torch.float32).view(1, -1, 1)
     z = torch.arange(res[2], dtype=torch.float32).view(1, 1, -1)
@@ -204,7 +205,9 @@ def test_sharded_reconstruction_world2_gloo(tmp_path, res, world):
         d = torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r), weights_only=True)
         assert torch.equal(d['vol'], expect), r                     # every rank holds the whole volume
         seen += [tuple(c) for c in d['calls']]
-    assert sorted(seen)[0][0] == 0 and sorted(seen)[-1][1] == res[0] and len(seen) == world   # each slab evaluated once
+    seen.sort()                                                    # the pieces tile [0, X) exactly once
+    assert seen[0][0] == 0 and seen[-1][1] == res[0]
+    assert all(a[1] == b[0] for a, b in zip(seen[:-1], seen[1:]))
 
 
 _SWAP_SCRIPT = r'''

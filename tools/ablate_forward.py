@@ -13,8 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'tools', 'microbench', 'ablate')
-MASKS = {'full': 0, 'no_gather': 1, 'no_activation': 2, 'no_gather_no_activation': 3, 'no_mfma': 4}
-FLAG_VARIANTS = {'full_noslp': ['-fno-slp-vectorize']}
+MASKS = {'full': 0}
+FLAG_VARIANTS = {'full_slp': ['-fslp-vectorize']}
 
 if sys.argv[1] == 'build':
     from latent_feature_grid_compression_amd.build import build_variant
