@@ -20,14 +20,27 @@
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
-// x[0..8) fp32 -> hi / lo f16 fragments
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// x[0..8) fp32 -> hi / lo f16 fragments, 3 VALU instructions per value: one packed RNE conversion per pair for each
+// of hi and lo, the hi halves converted back with a plain and an SDWA (upper-word) v_cvt_f32_f16, one subtraction.
+// (Plain C++ casts cost 4 per value: hipcc converts every hi half twice.)
 __device__ __forceinline__ void lfgc_split8(const float* __restrict__ x, h16x8& hi, h16x8& lo) {
+    u32x4 hp, lp;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const _Float16 h = (_Float16)x[t];
-        hi[t] = h;
-        lo[t] = (_Float16)(x[t] - (float)h);
+    for (int t = 0; t < 4; ++t) {
+        unsigned h, l;
+        float f0, f1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x[2 * t]), "v"(x[2 * t + 1]));
+        asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(f0) : "v"(h));
+        asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(h));
+        const float r0 = x[2 * t] - f0, r1 = x[2 * t + 1] - f1;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
+        hp[t] = h;
+        lp[t] = l;
     }
+    hi = __builtin_bit_cast(h16x8, hp);
+    lo = __builtin_bit_cast(h16x8, lp);
 }
 
 // One hidden layer on a 32-sample tile.  LAST = false: outputs the next layer's fragments; LAST = true: folds the

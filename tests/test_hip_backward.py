@@ -30,10 +30,12 @@ def _grads_vs(model, ref_named, tol, what=''):
     return worst
 
 
+@pytest.mark.parametrize('precision', ['f16x2', 'fp32'])
 @pytest.mark.parametrize('name', ['fwd_c4g15h16l3.npz', 'fwd_c6g17h32l4.npz'])
-def test_backward_matches_reference_fixture(dev, name):
+def test_backward_matches_reference_fixture(dev, name, precision):
     g = np.load(os.path.join(GOLD, name))
     m = build_from_golden(g, dev).train()
+    m.precision = precision
     pos = torch.from_numpy(g['pos']).to(dev).requires_grad_(True)      # training.py:99 sets requires_grad on positions
     y = m(pos)
     loss = torch.nn.functional.mse_loss(y.squeeze(-1), torch.from_numpy(g['target']).to(dev))

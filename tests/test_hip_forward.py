@@ -151,10 +151,15 @@ def test_wavelet_noncubic_and_adjoint(dev):
 FWD = ['fwd_cfg1_c16g16h32l2.npz', 'fwd_c4g15h16l3.npz', 'fwd_c6g17h32l4.npz', 'fwd_c2g32h64l4.npz']
 
 
+PRECISIONS = ['f16x2', 'fp32']      # layer-GEMM arithmetic of the fused kernel (include/lfgc.h); both must meet 1e-5
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('name', FWD)
-def test_forward_matches_reference_fixture(dev, name):
+def test_forward_matches_reference_fixture(dev, name, precision):
     g = np.load(os.path.join(GOLD, name))
     m = build_from_golden(g, dev)
+    m.precision = precision
     m.train()
     with torch.no_grad():
         dec = m.decode_volume()
@@ -192,7 +197,8 @@ def _decode_stash(stash, n, KS0, L, MT):
     return x0[:n], pre[:, :n]
 
 
-def test_stash_holds_reference_preactivations(dev):
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_stash_holds_reference_preactivations(dev, precision):
     """The values saved for backward are the reference's layer-0 input and pre-activations."""
     from latent_feature_grid_compression_amd import ops
     g = np.load(os.path.join(GOLD, 'fwd_cfg1_c16g16h32l2.npz'))
@@ -200,7 +206,7 @@ def test_stash_holds_reference_preactivations(dev):
     pos = torch.from_numpy(g['pos']).to(dev)
     with torch.no_grad():
         grid = m._decoded_channel_last()
-        y, stash = ops.forward_raw(m._descriptor(), grid, m._packed(), pos=pos, want_stash=True)
+        y, stash = ops.forward_raw(m._descriptor(), grid, m._packed(), pos=pos, want_stash=True, precision=precision)
     C, G, H, L, nf = [int(v) for v in g['meta']]
     x0, pre = _decode_stash(stash, pos.shape[0], (16 + 16) // 2, L, 1)
     # packed column order of layer 0 -> reference column order [p, emb, feat]
@@ -227,8 +233,10 @@ def test_stash_holds_reference_preactivations(dev):
     (3, 15, 100, 1, 77, 1e-5),         # padding everywhere: C 3->8, H 100->128, one layer, N < one tile
     (32, 20, 128, 8, 4096, 2e-5),      # deepest supported net
 ])
-def test_forward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n, tol):
+@pytest.mark.parametrize('precision', PRECISIONS)
+def test_forward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n, tol, precision):
     m, sm = build_synth(C, G, H, L, seed=4000 + C + G + H, dev=dev)
+    m.precision = precision
     rng = np.random.default_rng(C * 1000 + G)
     pos = torch.from_numpy(rng.uniform(-1, 1, (n, 3)).astype(np.float32))
     pos[:8] = torch.tensor([[sx, sy, sz] for sx in (-1., 1.) for sy in (-1., 1.) for sz in (-1., 1.)])[:min(8, n)]
@@ -245,6 +253,8 @@ def test_forward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n, tol):
                               [w.numpy() for w in sm['weights']], [b.numpy() for b in sm['biases']], pos[sub].numpy(), 2)
     e_hip, e_cpu = rel_err(y[sub], y64), rel_err(yref[sub], y64)
     assert e_hip <= max(3 * e_cpu, 3e-6), (e_hip, e_cpu)
+    print('precision %s C%d G%d H%d L%d: HIP vs fp64 %.2e, torch-CPU vs fp64 %.2e, HIP vs torch-CPU %.2e'
+          % (precision, C, G, H, L, e_hip, e_cpu, rel_err(y, yref)))
 
 
 def test_cfg5_grid_three_level_code_and_large_lattice(dev):
