@@ -38,7 +38,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, den
 F16_MFMA_PEAK_TFLOPS = 2500.0      # same guide, dense BF16/F16 MFMA
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r1/*pmc_hbm*.json):
 # 2 x FETCH_SIZE (gfx950 correction for 16-B/lane reads) + WRITE_SIZE, per (workload, precision); None = not collected
-TRAFFIC_BYTES = {}
+TRAFFIC_BYTES = {('headline', 'f16x2'): 396647584, ('headline', 'fp32'): 371994816}
 HBM_PEAK_GBS = 8000.0              # same guide, HBM3E spec
 
 WORKLOADS = {
@@ -73,7 +73,9 @@ def build_model(w, seed, device):
 def cpu_baseline(model, w, budget_s=20.0):
     """Oracle (op-for-op torch restatement of the reference) on the host cores, bounded sample of the workload."""
     from oracle import ref_torch as R
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one-GPU jobs a 16-CPU share of its 256 hardware threads; torch oversubscribed to 256 threads
+    # runs this path 70x slower (tools/microbench/cpu_threads.py: 4..32 threads all give ~0.5 Msamples/s)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     coeffs = [p.detach().cpu() for p in model.feature_grid]
     layers = list(model.net_layers) + [model.final_layer]
     weights = [l.weight.detach().cpu() for l in layers]
