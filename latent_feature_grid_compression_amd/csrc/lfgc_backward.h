@@ -583,10 +583,12 @@ static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcR
 template <int CH, int MT, int NF, int WAVES>
 static int lfgc_launch_bwd_data(const LfgcBwdArgs& a, int lds_bytes, int grid_data, hipStream_t stream) {
     auto kd = lfgc_bwd_data_kernel<CH, MT, NF, WAVES>;
-    if (lds_bytes > 64 * 1024) {
+    static int lds_limit_set = 0;
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
+        lds_limit_set = lds_bytes;
     }
     hipLaunchKernelGGL(kd, dim3(grid_data), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();
@@ -607,10 +609,12 @@ static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int wav
         constexpr int TPWM = TPW0 > TPW1 ? TPW0 : TPW1;
         const int comb_bytes = 4 * TPWM * 17 * 64 * 4;
         auto kw = lfgc_bwd_weight_kernel<CH, MT, NF>;
-        if (comb_bytes > 64 * 1024) {
+        static int comb_limit_set = 0;
+        if (comb_bytes > 64 * 1024 && comb_bytes > comb_limit_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kw),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, comb_bytes);
             if (e != hipSuccess) return (int)e;
+            comb_limit_set = comb_bytes;
         }
         hipLaunchKernelGGL(kw, dim3(grid_w), dim3(512), comb_bytes, stream, w);
     }

@@ -390,10 +390,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
 template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
 static int lfgc_launch_fwd_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
     auto kern = lfgc_fwd_kernel<CH, MT, NF, WAVES, STREAM, STASH>;
-    if (lds_bytes > 64 * 1024) {
+    static int lds_limit_set = 0;          // per instantiation; raised once (also keeps launches graph-capturable)
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
+        lds_limit_set = lds_bytes;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--no-input-grad', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='capture one train step in a HIP graph and replay it')
     args = ap.parse_args()
     from latent_feature_grid_compression_amd.data.Interpolation import trilinear_f_interpolation
     from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
@@ -31,15 +32,19 @@ def main():
     rng = np.random.Generator(np.random.PCG64(1003))
     vol = torch.from_numpy(rng.uniform(-1, 1, (255, 255, 255)).astype(np.float32)).to(dev)
     ds = IndexDataset((255, 255, 255), 16, build_index_table=False)
-    opt = torch.optim.Adam(model.parameters(), lr=0.008)
+    opt = torch.optim.Adam(model.parameters(), lr=0.008, capturable=args.graph)
     loss_fn = torch.nn.MSELoss()
     n = 2048 * 16
-    mn, mx, rs = ds.min_idx, ds.max_idx, ds.vol_res
+    mn, mx, rs = ds.min_idx.clone(), ds.max_idx.clone(), ds.vol_res.clone()      # host copies for the GT sampler's bounds
+    ds.min_idx, ds.max_idx, ds.scales = ds.min_idx.to(dev), ds.max_idx.to(dev), ds.scales.to(dev)   # no H2D inside the step
 
     def step(i, backward=True):
-        g = torch.Generator(device=dev)
-        g.manual_seed(3003 + i)
-        flat = torch.randint(0, ds.n_voxels, (n,), device=dev, generator=g)
+        if args.graph:
+            flat = torch.randint(0, ds.n_voxels, (n,), device=dev)        # default generator: graph-safe philox state
+        else:
+            g = torch.Generator(device=dev)
+            g.manual_seed(3003 + i)
+            flat = torch.randint(0, ds.n_voxels, (n,), device=dev, generator=g)
         raw = ds.lattice_from_flat(flat)
         _, norm = ds.positions_for(raw)
         norm.requires_grad = not args.no_input_grad
@@ -53,6 +58,32 @@ def main():
         return loss
 
     out = {}
+    if args.graph:
+        # whole step (sampler -> forward -> GT -> MSE -> backward -> Adam) captured once, replayed: removes the ~60 host
+        # launches per step; the C-ABI entry points neither allocate nor synchronise, so they capture like torch's own ops
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(3):
+                step(i)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = step(0)
+        for _ in range(args.warmup):
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        out['train_step_graph'] = {'ms_per_step': dt * 1e3, 'Msamples_per_s': n / dt / 1e6}
+        out['final_loss'] = float(static_loss)
+        out['config'] = 'cfg3 train step replayed from one HIP graph (same work as train_step)'
+        print(json.dumps(out))
+        return
     for name, bw in (('fwd_only', False), ('train_step', True)):
         for i in range(args.warmup):
             step(i, bw)
