@@ -62,6 +62,12 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and 'LFGC_LIB_PATH' not in os.environ:
+        try:                                   # fresh checkout: build in-tree (hipcc, gfx950); still no CPU fallback
+            from .build import build
+            build(verbose=False)
+        except Exception:                      # noqa: BLE001
+            pass
     if not os.path.exists(LIB_PATH):
         raise LfgcError('liblfgc.so not found at %s: build it with `python -m latent_feature_grid_compression_amd.build` '
                         '(hipcc, gfx950). There is no CPU fallback for the HIP path.' % LIB_PATH)

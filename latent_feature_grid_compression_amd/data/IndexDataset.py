@@ -55,3 +55,24 @@ class IndexDataset(torch.utils.data.Dataset):
         flat = torch.randint(0, self.n_voxels, (self.sample_size,))
         raw = self.volume_indices[flat] if self.volume_indices is not None else self.lattice_from_flat(flat)
         return self.positions_for(raw)
+
+
+class DeviceLatticeSampler:
+    """On-device counterpart of DataLoader(IndexDataset) (training/training.py:188-189, data/IndexDataset.py:90-96):
+    draws ``n`` random voxel-lattice points per call directly on the GPU (no (n_voxels, 3) table, no worker processes,
+    no H2D copies) and returns ``(raw_positions (n,3), normalized_positions (n,3))`` with the reference's arithmetic.
+    Everything it launches is stream-ordered, so a train step using it can be captured in a HIP graph."""
+
+    def __init__(self, volume_shape, device):
+        self.ds = IndexDataset(tuple(int(v) for v in volume_shape), 1, build_index_table=False)
+        self.device = torch.device(device)
+        self.min_idx = self.ds.min_idx.to(self.device)
+        self.max_idx = self.ds.max_idx.to(self.device)
+        self.scales = self.ds.scales.to(self.device)
+        self.n_voxels = self.ds.n_voxels
+
+    def sample(self, n: int, generator=None):
+        flat = torch.randint(0, self.n_voxels, (int(n),), device=self.device, generator=generator)
+        raw = self.ds.lattice_from_flat(flat)
+        norm = normalize_volume(raw, self.min_idx.unsqueeze(0), self.max_idx.unsqueeze(0), -1.0, 1.0)
+        return raw, self.scales.unsqueeze(0) * norm

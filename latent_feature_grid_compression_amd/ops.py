@@ -117,9 +117,7 @@ def decode_levels(coeffs: Sequence[torch.Tensor], shape_array, filter_rev: torch
                   channel_last: bool) -> torch.Tensor:
     """All IDWT levels (model/Feature_Grid_Model.py:102-108, drop layers already applied by the caller);
     optionally followed by the conversion to the sampler's channel-last layout."""
-    if len(coeffs) < 2:
-        raise ValueError('a wavelet-coded grid needs at least one detail level')
-    restored = coeffs[0]
+    restored = coeffs[0]          # grids smaller than 6 voxels have no wavelet level at all (dwt_max_level = 0)
     for hf, shape in zip(coeffs[1:], shape_array):
         restored = idwt_level(restored, hf, filter_rev, shape)
     return to_channel_last(restored) if channel_last else restored
@@ -135,7 +133,9 @@ class DecodeVolumeFn(torch.autograd.Function):
         ctx.channel_last = bool(channel_last)
         ctx.dims = [tuple(c.shape) for c in coeffs]
         with torch.no_grad():
-            return decode_levels([c.detach() for c in coeffs], ctx.shape_array, filter_rev, ctx.channel_last)
+            out = decode_levels([c.detach() for c in coeffs], ctx.shape_array, filter_rev, ctx.channel_last)
+            # zero levels and channel-first: the output would alias the parameter; hand autograd a fresh tensor
+            return out.clone() if out.data_ptr() == coeffs[0].data_ptr() else out
 
     @staticmethod
     def backward(ctx, d_out):
