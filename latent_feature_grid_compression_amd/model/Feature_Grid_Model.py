@@ -32,7 +32,9 @@ class Feature_Grid_Model(nn.Module):
         self.filter = wavelet_filter
 
         features, shapes = self.encode_volume(feature_grid, num_levels=num_levels)
-        self.feature_grid = nn.ParameterList([nn.Parameter(f, requires_grad=True) for f in features])
+        # the reference keeps the detail bands as strided views of the encoder output (filtered[0, :, 1:]); stored
+        # contiguous here (same values, same shapes) so the kernels bind them without a per-call copy
+        self.feature_grid = nn.ParameterList([nn.Parameter(f.contiguous(), requires_grad=True) for f in features])
         self.shape_array = shapes
 
         if drop_layer is None:
