@@ -148,6 +148,7 @@ int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
 
 /* Backward of lfgc_forward_f32 (what autograd derives for model/Feature_Grid_Model.py:62-75;
  * triggered at training/training.py:137).  positions->pos must be non-NULL.
+ *   precision   LFGC_PRECISION_* for the data-gradient chain dH_{l-1} = W_l^T dA_l (weight gradients: exact fp32)
  *   stash       device, written by the forward call with the same inputs
  *   d_out       device (N)
  *   d_grid_cl   device (D,H,W,Cs)  ACCUMULATED into with float atomics (caller zeroes it)
@@ -158,7 +159,7 @@ int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
 int64_t lfgc_backward_workspace_bytes(const lfgc_mlp_desc* desc, int64_t n_samples);
 int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
                       const float* grid_cl, int D, int H, int W,
-                      const float* packed, const float* stash, const float* d_out,
+                      const float* packed, int precision, const float* stash, const float* d_out,
                       float* d_grid_cl, float* const* d_weights, float* const* d_biases, float* d_pos,
                       void* workspace, int64_t workspace_bytes, lfgc_stream_t stream);
 

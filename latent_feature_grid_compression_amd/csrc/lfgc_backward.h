@@ -17,6 +17,7 @@
 //   3. lfgc_bwd_reduce_kernel  sums the slabs into the nn.Linear-shaped gradients (deterministic, no atomics).
 #pragma once
 #include "lfgc_common.h"
+#include "lfgc_forward16.h"      // h16x8, lfgc_split8
 
 struct LfgcBwdArgs {
     const float* pos;          // (N,3)
@@ -70,7 +71,53 @@ __device__ __forceinline__ void lfgc_snake_bwd(const float* __restrict__ slot, c
 // One workgroup per CU (WAVES = 8 when every CU gets a 256-sample batch, else 4); the transposed weight images
 // stream through a 2-deep LDS ring by LDS-DMA exactly like the forward's (image of step t+1 in flight while step
 // t computes, one barrier per step); the scatter staging aliases the ring slot that has just been consumed.
-template <int CH, int MT, int NF, int WAVES>
+// acc += Wt_tile . dA for one 32-row tile with f16-split operands (three MFMAs per 16-wide k-step); `arow` = LDS
+// address of (row 32m + lane&31, lane half's 32 bytes of k-step 0).
+template <int KS16>
+__device__ __forceinline__ f32x16 lfgc_mfma_tile16(const float* __restrict__ arow, const h16x8 (&Fhi)[KS16],
+                                                   const h16x8 (&Flo)[KS16], f32x16 acc) {
+#pragma unroll
+    for (int ks = 0; ks < KS16; ++ks) {
+        const h16x8 whi = *reinterpret_cast<const h16x8*>(arow + 16 * ks);
+        const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, Fhi[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Flo[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Fhi[ks], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// Gradients span many orders of magnitude and are small: before the f16 hi/lo split each wave scales its 32-sample
+// tile of dA by a power of two that brings the tile maximum to [2^13, 2^14) (so that the lo halves, 2^-11 of the hi,
+// do not fall off the bottom of the f16 range); the product is scaled back exactly.  Returns the scale, writes 1/scale.
+template <int NV>
+__device__ __forceinline__ float lfgc_tile_pow2_scale(const float (&v)[NV], float& inv) {
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; i += 2) amax = lfgc_absmax3(amax, v[i], v[i + 1]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    const int e = (__float_as_int(amax) >> 23) & 255;            // amax = 1.x * 2^(e - 127); e == 0: zero tile
+    int k = (e == 0 || e == 255) ? 0 : (13 + 127 - e);
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    inv = __int_as_float((127 - k) << 23);
+    return __int_as_float((127 + k) << 23);
+}
+
+template <int NF16>
+__device__ __forceinline__ void lfgc_split_scaled(const float* __restrict__ v, float sc, h16x8 (&Fhi)[NF16], h16x8 (&Flo)[NF16]) {
+#pragma unroll
+    for (int f = 0; f < NF16; ++f) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = v[8 * f + u] * sc;
+        lfgc_split8(t, Fhi[f], Flo[f]);
+    }
+}
+
+// H16 = false: exact f32 MFMA chain.  H16 = true: the chain's GEMMs run f16-split like the default forward build
+// (dA carried as f16 hi+lo fragments, transposed weight images pre-split and scaled; fp32 accumulate, scaled back).
+template <int CH, int MT, int NF, int WAVES, bool H16>
 __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs a) {
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
@@ -94,7 +141,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_final = smem;               // Wf (HP) | bf (4)
-    float* s_ring = smem + HP + 4;       // 2 x SLOT: transposed weight images / scatter staging
+    float* s_inv = smem + HP + 4;        // 1 / scale per layer (f16-split build), 8 floats
+    float* s_ring = s_inv + 8;           // 2 x SLOT: transposed weight images / scatter staging
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, hh = lane >> 5;
@@ -109,9 +157,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         for (int i = tid; i < (HP + 4) / 4; i += NT) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
     }
     // image sequence per batch: W_{L-1}^T, ..., W_1^T (TB1 each), then W_0^T (TB0)
+    constexpr int K0P16 = (K0P + 15) / 16 * 16;
+    constexpr int HBLK0 = HP * (K0P16 + 4) + HP, HBLK1 = HP * (HP + 4) + HP;
+    const int off_h = off_t + TB0 + (L - 1) * TB1;            // scales, then the f16-split forward blocks (lfgc_common.h)
+    const int off_img = H16 ? off_h + 16 + HBLK0 + (L - 1) * HBLK1 : off_t;
     auto image_src = [&](int l) -> const float* {
-        return l == 0 ? a.packed + off_t : a.packed + off_t + TB0 + (long long)(l - 1) * TB1;
+        return l == 0 ? a.packed + off_img : a.packed + off_img + TB0 + (long long)(l - 1) * TB1;
     };
+    if (tid < LFGC_MAX_LAYERS) s_inv[tid] = a.packed[off_h + 8 + tid];      // all LDS lives in the one dynamic array
     lfgc_dma_to_lds(image_src(L - 1), s_ring, (L - 1) == 0 ? TB0 : TB1, wave, lane, WAVES);
     __syncthreads();
     unsigned step = 0;
@@ -153,15 +206,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             lfgc_snake_bwd<MT>(st_tile + 64 * KS0 + (long long)l * (64 * 16 * MT), dH, dA, lane);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[(long long)l * (64 * 16 * MT) + i * 64 + lane] = dA[i];
-            const float* s_row = acquire(l) + j * ST + 4 * hh;
+            if (H16) {
+                h16x8 Fhi[2 * MT], Flo[2 * MT];
+                float isc;
+                const float sc = lfgc_tile_pow2_scale<16 * MT>(dA, isc);
+                lfgc_split_scaled<2 * MT>(dA, sc, Fhi, Flo);
+                const float* s_row = acquire(l) + j * ST + 8 * hh;
+                const float is = s_inv[l] * isc;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x16 acc;
+                for (int m = 0; m < MT; ++m) {
+                    f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    acc = lfgc_mfma_tile16<2 * MT>(s_row + 32 * m * ST, Fhi, Flo, acc);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dH[16 * m + r] = acc[r];
+                    for (int r = 0; r < 16; ++r) dH[16 * m + r] = acc[r] * is;
+                }
+            } else {
+                const float* s_row = acquire(l) + j * ST + 4 * hh;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                    acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dH[16 * m + r] = acc[r];
+                }
             }
         }
 
@@ -172,16 +243,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             lfgc_snake_bwd<MT>(st_tile + 64 * KS0, dH, dA, lane);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[i * 64 + lane] = dA[i];
-            const float* s_row = acquire(0) + j * ST + 4 * hh;
+            h16x8 Fhi[2 * MT], Flo[2 * MT];
+            float isc = 1.0f;
+            if (H16) {
+                const float sc = lfgc_tile_pow2_scale<16 * MT>(dA, isc);
+                lfgc_split_scaled<2 * MT>(dA, sc, Fhi, Flo);
+            }
+            const float* s_row = acquire(0) + j * ST + (H16 ? 8 : 4) * hh;
+            const float is = H16 ? s_inv[0] * isc : 1.0f;
 #pragma unroll
             for (int m = 0; m < TXA; ++m) {
                 if (m < TXF || a.d_pos) {            // scalar-input rows only when d_pos is wanted (wave-uniform)
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
+                    if (H16) acc = lfgc_mfma_tile16<2 * MT>(s_row + 32 * m * ST, Fhi, Flo, acc);
+                    else acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dX[16 * m + r] = acc[r];
+                    for (int r = 0; r < 16; ++r) dX[16 * m + r] = acc[r] * is;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dX[16 * m + r] = 0.0f;
@@ -580,9 +659,9 @@ static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcR
     if (q == 0 && idx < total) *dst = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
 }
 
-template <int CH, int MT, int NF, int WAVES>
+template <int CH, int MT, int NF, int WAVES, bool H16>
 static int lfgc_launch_bwd_data(const LfgcBwdArgs& a, int lds_bytes, int grid_data, hipStream_t stream) {
-    auto kd = lfgc_bwd_data_kernel<CH, MT, NF, WAVES>;
+    auto kd = lfgc_bwd_data_kernel<CH, MT, NF, WAVES, H16>;
     static int lds_limit_set = 0;
     if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd),
@@ -597,10 +676,13 @@ static int lfgc_launch_bwd_data(const LfgcBwdArgs& a, int lds_bytes, int grid_da
 
 // waves = waves per workgroup of the data kernel (4 or 8, chosen by the caller together with a.nbatches)
 template <int CH, int MT, int NF>
-static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int waves, int lds_bytes, int grid_data,
+static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int waves, int h16, int lds_bytes, int grid_data,
                            int grid_w, hipStream_t stream) {
-    const int rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8>(a, lds_bytes, grid_data, stream)
-                              : lfgc_launch_bwd_data<CH, MT, NF, 4>(a, lds_bytes, grid_data, stream);
+    int rc;
+    if (h16) rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, true>(a, lds_bytes, grid_data, stream)
+                             : lfgc_launch_bwd_data<CH, MT, NF, 4, true>(a, lds_bytes, grid_data, stream);
+    else rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, false>(a, lds_bytes, grid_data, stream)
+                         : lfgc_launch_bwd_data<CH, MT, NF, 4, false>(a, lds_bytes, grid_data, stream);
     if (rc != LFGC_OK) return rc;
     {
         constexpr int K0R_ = (CH + (3 + 6 * NF + 7) / 8 * 8 + 31) / 32 * 32;

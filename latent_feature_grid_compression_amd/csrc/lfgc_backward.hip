@@ -1,10 +1,10 @@
 // lfgc_backward.hip -- C-ABI entry for the backward of the fused path: checks, workspace carving, dispatch.
 #include "lfgc_backward.h"
 
-int lfgc_bwd_dispatch_ch8(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
-int lfgc_bwd_dispatch_ch16(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
-int lfgc_bwd_dispatch_ch24(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
-int lfgc_bwd_dispatch_ch32(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch8(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch16(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch24(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
+int lfgc_bwd_dispatch_ch32(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
 
 namespace {
 const int kMaxSlabs = 256;          // workgroups of the weight-gradient kernel (one partial slab each)
@@ -37,12 +37,13 @@ extern "C" int64_t lfgc_backward_workspace_bytes(const lfgc_mlp_desc* desc, int6
 
 extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
                                  const float* grid_cl, int D, int H, int W,
-                                 const float* packed, const float* stash, const float* d_out,
+                                 const float* packed, int precision, const float* stash, const float* d_out,
                                  float* d_grid_cl, float* const* d_weights, float* const* d_biases, float* d_pos,
                                  void* workspace, int64_t workspace_bytes, lfgc_stream_t stream) {
     if (!desc || !positions || !grid_cl || !packed || !stash || !d_out || !d_grid_cl || !d_weights || !d_biases)
         return LFGC_E_NULL;
     if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
+    if (precision != LFGC_PRECISION_F32 && precision != LFGC_PRECISION_F16X2) return LFGC_E_UNSUPPORTED;
     if (!positions->pos) return LFGC_E_NULL;            // backward runs on explicit positions only
     if (positions->n < 0 || D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
     if ((((uintptr_t)grid_cl) | ((uintptr_t)packed) | ((uintptr_t)stash) | ((uintptr_t)d_grid_cl) | ((uintptr_t)workspace)) & 15)
@@ -92,16 +93,16 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     const int tb0 = p.K0R * p.ST, tb1 = p.HP * p.ST, sc = waves * 32 * (p.CH + 4 + 16);
     int slot = tb0 > tb1 ? tb0 : tb1;
     if (sc > slot) slot = sc;
-    const int lds_bytes = (p.HP + 4 + 2 * slot) * 4;
+    const int lds_bytes = (p.HP + 4 + 8 + 2 * slot) * 4;
     long long grid_data = cus;
     if (grid_data > a.nbatches) grid_data = a.nbatches;
 
     int rc;
     switch (p.CH) {
-        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, waves, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
         default: return LFGC_E_UNSUPPORTED;
     }
     if (rc != LFGC_OK) return rc;

@@ -38,6 +38,7 @@ struct LfgcPlan {
     // hold, per 16-column k-step, [lane half 0: 8 hi halfs | 8 lo halfs][lane half 1: 8 hi | 8 lo] (64 B), i.e.
     // 4 bytes per weight like the fp32 blocks, same +16 B row padding, followed by the scaled fp32 bias.
     int K0P16, SH0, SH1, blkh0, blkh1, off_h, off_hblk;
+    int off_ht;              // f16-split TRANSPOSED images for the backward data chain (same sizes as tblk0 / tblk1)
 };
 
 __host__ __device__ inline int lfgc_roundup(int v, int m) { return (v + m - 1) / m * m; }
@@ -72,7 +73,8 @@ __host__ __device__ inline LfgcPlan lfgc_make_plan(int C, int H, int L, int NF) 
     p.blkh1 = p.HP * p.SH1 + p.HP;
     p.off_h = p.off_t + p.tblk0 + (L - 1) * p.tblk1;         // 16 floats: scale[8] | 1/scale[8]
     p.off_hblk = p.off_h + 16;
-    p.total_floats = p.off_hblk + p.blkh0 + (L - 1) * p.blkh1;
+    p.off_ht = p.off_hblk + p.blkh0 + (L - 1) * p.blkh1;
+    p.total_floats = p.off_ht + p.tblk0 + (L - 1) * p.tblk1;
     p.stash_tile_floats = 64 * (p.KS0 + L * 16 * p.MT);
     return p;
 }

@@ -189,6 +189,33 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
             if (ki < p.H && ho < p.H) v = a.w[l][ho * p.H + ki];
         } else if (idx < p.off_hblk) {
             continue;                                         // scales: written by pack_scale_kernel
+        } else if (idx >= p.off_ht) {                         // f16-split transposed images: [row = k_in][k = h_out]
+            const int o = idx - p.off_ht;
+            const int l = o < p.tblk0 ? 0 : 1 + (o - p.tblk0) / p.tblk1;
+            const int oo = o < p.tblk0 ? o : (o - p.tblk0) % p.tblk1;
+            const int row = oo / p.ST, q = oo % p.ST;
+            const float scale = a.packed[p.off_h + l];
+            unsigned bits = 0;
+            const int in_col = (l == 0) ? (row < p.K0P ? lfgc_layer0_src_col(p, row) : -1) : (row < p.H ? row : -1);
+            if (in_col >= 0 && q < p.HP) {
+                const int b = q >> 4, t = q & 15;
+                const int hp = t >> 3, part = (t >> 2) & 1, pair = t & 3;
+                const int Kin = l == 0 ? (p.E + p.C) : p.H;
+                unsigned short hv[2] = {0, 0};
+                for (int u = 0; u < 2; ++u) {
+                    const int jj = 2 * pair + u;
+                    const int ho = 16 * b + (jj & 3) + 8 * (jj >> 2) + 4 * hp;       // contraction index = h_out
+                    if (ho < p.H) {
+                        const float w = a.w[l][ho * Kin + in_col] * scale;
+                        const _Float16 hi = (_Float16)w;
+                        const _Float16 lo = (_Float16)(w - (float)hi);
+                        const _Float16 x = part ? lo : hi;
+                        hv[u] = *reinterpret_cast<const unsigned short*>(&x);
+                    }
+                }
+                bits = (unsigned)hv[0] | ((unsigned)hv[1] << 16);
+            }
+            v = __uint_as_float(bits);
         } else {                                              // f16-split blocks (hi | lo halves, scaled)
             const int o = idx - p.off_hblk;
             const int l = o < p.blkh0 ? 0 : 1 + (o - p.blkh0) / p.blkh1;

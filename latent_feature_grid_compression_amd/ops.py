@@ -207,7 +207,8 @@ def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos:
     return out, stash
 
 
-def backward_raw(desc: MlpDesc, grid_cl, packed, pos, stash, d_out, weights, biases, need_d_pos: bool):
+def backward_raw(desc: MlpDesc, grid_cl, packed, pos, stash, d_out, weights, biases, need_d_pos: bool,
+                 precision: str = 'f16x2'):
     lib = _lib.load()
     pos = _f32c(pos)
     d_out = _f32c(d_out)
@@ -223,7 +224,7 @@ def backward_raw(desc: MlpDesc, grid_cl, packed, pos, stash, d_out, weights, bia
     wp, _k1 = _lib.ptr_array([w.data_ptr() for w in d_w])
     bp, _k2 = _lib.ptr_array([b.data_ptr() for b in d_b])
     check(lib.lfgc_backward_f32(ctypes.byref(desc), ctypes.byref(ps), grid_cl.data_ptr(), D, H, W, packed.data_ptr(),
-                                stash.data_ptr(), d_out.data_ptr(), d_grid.data_ptr(), wp, bp,
+                                _lib.PRECISION[precision], stash.data_ptr(), d_out.data_ptr(), d_grid.data_ptr(), wp, bp,
                                 d_pos.data_ptr() if d_pos is not None else None, ws.data_ptr(), ws_bytes,
                                 _stream(grid_cl)), 'lfgc_backward_f32')
     return d_grid, d_w, d_b, d_pos
@@ -240,6 +241,7 @@ class SampleDecodeFn(torch.autograd.Function):
                                precision=precision)
         if need_grad:
             ctx.desc = desc
+            ctx.precision = precision
             ctx.n_layers = n_layers
             ctx.need_d_pos = pos.requires_grad
             ctx.save_for_backward(pos.detach(), grid_cl.detach(), packed, stash, *[p.detach() for p in params])
@@ -252,7 +254,7 @@ class SampleDecodeFn(torch.autograd.Function):
         L = ctx.n_layers
         weights, biases = params[:L + 1], params[L + 1:]
         d_grid, d_w, d_b, d_pos = backward_raw(ctx.desc, grid_cl, packed, pos, stash, d_y.reshape(-1), weights, biases,
-                                               ctx.need_d_pos)
+                                               ctx.need_d_pos, precision=ctx.precision)
         return (None, d_pos, d_grid, None, None, None) + tuple(d_w) + tuple(d_b)
 
 
