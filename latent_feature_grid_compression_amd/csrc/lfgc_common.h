@@ -9,8 +9,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LFGC_WAVE 64
 #define LFGC_TILE_SAMPLES 32          // samples per wave tile (N dimension of v_mfma_f32_32x32x2_f32)
-#define LFGC_WG_WAVES 4
-#define LFGC_WG_SAMPLES (LFGC_TILE_SAMPLES * LFGC_WG_WAVES)
 
 // ------------------------------------------------------------------------------------------------
 // Packed-parameter plan.  Everything is derived from the descriptor; host and device agree through
