@@ -80,6 +80,67 @@ int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, float* out,
                        int C, int n0, int n1, int n2, lfgc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pruning ("drop") layers on the wavelet coefficients
+ *
+ * Every drop layer of the reference multiplies a coefficient tensor (C, ...) by a per-coefficient factor m of
+ * shape (...) that is shared by all channels (`x.mul(self.betas.unsqueeze(0))` and relatives):
+ *   SmallifyDropout.forward                        model/Smallify_Dropout.py:54-61         m = betas | d_mask
+ *   Straight_Through_Dropout.forward               model/Straight_Through_Dropout.py:26-30  m = (rand < mask_values)
+ *   MaskedWavelet_Straight_Through_Dropout.forward model/Straight_Through_Dropout.py:54-62  m = sigmoid(mask_values), thr
+ *   VariationalDropout.forward                     model/Variational_Dropout_Layer.py:101-112  m = theta + sigma*xi | d_mask
+ * `threshold` selects the value rule: NaN -> value = x*m; otherwise the masked straight-through rule
+ * value = (x*(m >= threshold) - x*m) + x*m (forward value of the hard mask, gradient of the soft one).
+ * In both rules the gradients are d_x = g*m and d_m = sum over channels of g*x.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* lfgc_idwt_level_f32 with the drop layers of its inputs folded in (model/Feature_Grid_Model.py:103, :105):
+ *   mul_lll device (d0,d1,d2) or NULL     factor of the low band (only the coarsest level has one: drop[0])
+ *   mul_hf  device (7, d0,d1,d2) or NULL  factor of the detail bands (drop[level]) */
+int lfgc_idwt_level_drop_f32(const float* lll, const float* hf, const float* mul_lll, float threshold_lll,
+                             const float* mul_hf, float threshold_hf, const float* filter_rev, float* out,
+                             int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
+
+/* Adjoint of lfgc_idwt_level_drop_f32: d_lll / d_hf are the gradients of the UN-multiplied inputs;
+ * d_mul_lll (d0,d1,d2) / d_mul_hf (7,d0,d1,d2) receive the factor gradients (NULL = not wanted; needs lll / hf). */
+int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* lll, const float* hf,
+                                 const float* mul_lll, const float* mul_hf, float* d_lll, float* d_hf,
+                                 float* d_mul_lll, float* d_mul_hf, int C, int d0, int d1, int d2,
+                                 int t0, int t1, int t2, lfgc_stream_t stream);
+
+/* One drop layer on one tensor outside the decode (the layers' own forward(x)): x, out (C, n), mul (n). */
+int lfgc_drop_apply_f32(const float* x, const float* mul, float threshold, float* out, int C, int64_t n,
+                        lfgc_stream_t stream);
+int lfgc_drop_apply_bwd_f32(const float* d_out, const float* x, const float* mul, float* d_x, float* d_mul /* or NULL */,
+                            int C, int64_t n, lfgc_stream_t stream);
+
+/* SmallifySignVarianceTracker.sign_variance_pruning_onlyVar (model/Smallify_Dropout.py:106-112) on DEVICE state:
+ * phi = sign(betas) - ema; ema += momentum*phi; emavar = (1 - momentum)*(emavar + momentum*phi^2), fp32, the
+ * reference's operation order (bit-identical state; the reference moves betas to the CPU every step). */
+int lfgc_sign_variance_update_f32(const float* betas, float* ema, float* emavar, float momentum, int64_t n,
+                                  lfgc_stream_t stream);
+
+/* Penalty terms of the pruning losses as ONE multi-tensor reduction (SmallifyLoss, model/Smallify_Dropout.py:21-40;
+ * VariationalDropoutLoss._collect_penalties + calculate_Dkl, model/Variational_Dropout_Layer.py:48-53, :115-122). */
+enum {
+    LFGC_PENALTY_L1 = 0,          /* sum |a|                 (l1_loss of betas / mask_values)               */
+    LFGC_PENALTY_L2 = 1,          /* sum a^2                 (torch.sum(torch.abs(f) ** 2) of a coefficient tensor) */
+    LFGC_PENALTY_DKL = 2          /* sum -k1*sigmoid(k2 + k3*la) + 0.5*softplus(-la) + k1, la = b - 2a (a = log_thetas, b = log_var) */
+};
+#define LFGC_PENALTY_MAX_TERMS 16
+typedef struct lfgc_penalty_term {
+    const float* a;               /* device */
+    const float* b;               /* device, DKL only */
+    int64_t n;
+    int32_t kind;
+} lfgc_penalty_term;
+/* terms: host array; sums: device double[n_terms], overwritten (fp64 accumulation). */
+int lfgc_penalty_sums_f32(const lfgc_penalty_term* terms, int n_terms, double* sums, lfgc_stream_t stream);
+/* Gradients: grad_a[t] (and grad_b[t] for DKL terms) are OVERWRITTEN with d_sums[t] * d(term t)/d(a | b);
+ * d_sums device float[n_terms]; grad_a / grad_b host arrays of device pointers. */
+int lfgc_penalty_grads_f32(const lfgc_penalty_term* terms, int n_terms, const float* d_sums,
+                           float* const* grad_a, float* const* grad_b, lfgc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused sample + Fourier-embed + MLP decoder
  * ---------------------------------------------------------------------------------------------- */
 

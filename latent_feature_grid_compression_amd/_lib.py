@@ -26,6 +26,12 @@ class Positions(Structure):
                 ('x_begin', c_int32), ('x_end', c_int32), ('tile', c_int32)]
 
 
+class PenaltyTerm(Structure):
+    _fields_ = [('a', c_void_p), ('b', c_void_p), ('n', c_int64), ('kind', c_int32)]
+
+
+PENALTY_L1, PENALTY_L2, PENALTY_DKL = 0, 1, 2
+PENALTY_MAX_TERMS = 16
 _PP = POINTER(c_void_p)
 
 # name -> (restype, argtypes); mirrors include/lfgc.h one to one
@@ -36,6 +42,14 @@ SIGNATURES = {
     'lfgc_idwt_level_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'lfgc_grid_layout_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     'lfgc_dwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'lfgc_idwt_level_drop_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_void_p] +
+                                 [c_int] * 7 + [c_void_p]),
+    'lfgc_idwt_level_drop_bwd_f32': (c_int, [c_void_p] * 10 + [c_int] * 7 + [c_void_p]),
+    'lfgc_drop_apply_f32': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_void_p]),
+    'lfgc_drop_apply_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    'lfgc_sign_variance_update_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    'lfgc_penalty_sums_f32': (c_int, [POINTER(PenaltyTerm), c_int, c_void_p, c_void_p]),
+    'lfgc_penalty_grads_f32': (c_int, [POINTER(PenaltyTerm), c_int, c_void_p, _PP, _PP, c_void_p]),
     'lfgc_mlp_supported': (c_int, [POINTER(MlpDesc)]),
     'lfgc_grid_channel_stride': (c_int, [c_int]),
     'lfgc_packed_bytes': (c_int64, [POINTER(MlpDesc)]),

@@ -18,10 +18,24 @@ struct IdwtArgs {
     const float* filt;  // (8,4,4,4)
     float* out;         // (C, t0,t1,t2)
     int C, d0, d1, d2, t0, t1, t2, o0, o1, o2;   // o = crop offset floor((2d+2-t)/2)
+    // DROP build only: the pruning layers' per-coefficient factors, shared by all channels
+    const float* mul_l; // (d0,d1,d2) or NULL
+    const float* mul_h; // (7, d0,d1,d2) or NULL
+    float thr_l, thr_h; // NaN: value = x * m;  else masked straight-through: value = (x*(m>=thr) - x*m) + x*m
 };
+
+// One coefficient through its drop layer (model/Smallify_Dropout.py:57, model/Variational_Dropout_Layer.py:109,
+// model/Straight_Through_Dropout.py:28 and :58 -- the latter op for op, so the value is the reference's bit for bit).
+__device__ __forceinline__ float drop_value(float x, float m, float thr, bool ste) {
+    if (!ste) return __fmul_rn(x, m);
+    const float hard = m >= thr ? 1.0f : 0.0f;
+    const float soft = __fmul_rn(x, m);
+    return __fadd_rn(__fsub_rn(__fmul_rn(x, hard), soft), soft);
+}
 
 // Synthesis: out_full[o] = sum_{s,t} in[s][i] F_s[t], o = 2 i + t per axis.  Thread = cell jj in [0,d] per axis:
 // it produces the 2x2x2 outputs o = 2 jj + p from the cells i = jj - e (e in {0,1}) with taps t = p + 2 e.
+template <bool DROP>
 __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
     // filter bank re-laid [tap][band] in LDS: the 8 bands of one tap are two broadcast ds_read_b128
     // (left in global memory hipcc fetches every tap with a per-lane vector load: 512 extra loads per thread)
@@ -49,11 +63,13 @@ __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
             const bool ok = iz >= 0 && iz < a.d0 && iy >= 0 && iy < a.d1 && ix >= 0 && ix < a.d2;
             const long long sp = ((long long)min(max(iz, 0), a.d0 - 1) * a.d1 + min(max(iy, 0), a.d1 - 1)) * a.d2 +
                                  min(max(ix, 0), a.d2 - 1);
-            const float l = in_l[sp];
+            float l = in_l[sp];
+            if (DROP && a.mul_l) l = drop_value(l, a.mul_l[sp], a.thr_l, a.thr_l == a.thr_l);
             v[e][0] = ok ? l : 0.0f;
 #pragma unroll
             for (int s = 1; s < 8; ++s) {
-                const float h = in_h[(long long)(s - 1) * dvol + sp];
+                float h = in_h[(long long)(s - 1) * dvol + sp];
+                if (DROP && a.mul_h) h = drop_value(h, a.mul_h[(long long)(s - 1) * dvol + sp], a.thr_h, a.thr_h == a.thr_h);
                 v[e][s] = ok ? h : 0.0f;
             }
         }
@@ -137,6 +153,102 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
     }
 }
 
+// Adjoint of the IDWT level WITH drop factors (autograd of "coefficients * factor -> conv_transpose3d"):
+//   adj_s[c][i]  = analysis of d_out (as analysis_kernel),   d_coef_s[c][i] = adj_s[c][i] * m_s[i],
+//   d_m_s[i]     = sum_c adj_s[c][i] * coef_s[c][i]          (the factor is shared by all channels).
+// Block = 4 channel slots (one wave each) x 64 cells; a wave walks the channels c = slot, slot+4, ... of its 64 cells,
+// keeps the 8 partial d_m in registers, and the 4 slots are combined through LDS in a fixed order: no atomics, the
+// result is bitwise repeatable.  The channel loop and the z-tap loop stay rolled (see idwt_level_kernel on LICM).
+struct AdjointDropArgs {
+    const float* src;      // d_out (C, n0,n1,n2)
+    const float* filt;
+    const float* lll;      // forward inputs: (C, d0,d1,d2)
+    const float* hf;       //                 (C, 7, d0,d1,d2)
+    const float* mul_l;    // (d0,d1,d2) or NULL
+    const float* mul_h;    // (7, d0,d1,d2) or NULL
+    float* d_lll;          // (C, d0,d1,d2)
+    float* d_hf;           // (C, 7, d0,d1,d2)
+    float* d_mul_l;        // (d0,d1,d2) or NULL
+    float* d_mul_h;        // (7, d0,d1,d2) or NULL
+    int C, n0, n1, n2, lo0, lo1, lo2, d0, d1, d2;
+};
+
+__global__ __launch_bounds__(256) void adjoint_drop_kernel(const AdjointDropArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_f[512];      // [tap][band]
+    __shared__ float s_red[3][8][64];                            // partial d_m of slots 1..3
+    for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
+    __syncthreads();
+    const long long dvol = (long long)a.d0 * a.d1 * a.d2;
+    const long long nvol = (long long)a.n0 * a.n1 * a.n2;
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    const long long cell = (long long)blockIdx.x * 64 + lane;
+    const bool valid = cell < dvol;
+    const long long cc = valid ? cell : dvol - 1;
+    const int ix = (int)(cc % a.d2);
+    const long long r = cc / a.d2;
+    const int iy = (int)(r % a.d1), iz = (int)(r / a.d1);
+    float m[8], dm[8];
+    m[0] = a.mul_l ? a.mul_l[cc] : 1.0f;
+#pragma unroll
+    for (int s = 1; s < 8; ++s) m[s] = a.mul_h ? a.mul_h[(long long)(s - 1) * dvol + cc] : 1.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) dm[s] = 0.0f;
+#pragma unroll 1
+    for (int c = slot; c < a.C; c += 4) {
+        const float* src = a.src + (long long)c * nvol;
+        float acc[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[s] = 0.0f;
+#pragma unroll 1
+        for (int tz = 0; tz < 4; ++tz) {
+            const int uz = 2 * iz + tz - a.lo0;
+            const bool okz = uz >= 0 && uz < a.n0;
+            const int cz = min(max(uz, 0), a.n0 - 1);
+            float v[16];
+#pragma unroll
+            for (int tyx = 0; tyx < 16; ++tyx) {
+                const int uy = 2 * iy + (tyx >> 2) - a.lo1, ux = 2 * ix + (tyx & 3) - a.lo2;
+                const bool ok = okz && uy >= 0 && uy < a.n1 && ux >= 0 && ux < a.n2;
+                const float x = src[((long long)cz * a.n1 + min(max(uy, 0), a.n1 - 1)) * a.n2 + min(max(ux, 0), a.n2 - 1)];
+                v[tyx] = ok ? x : 0.0f;
+            }
+#pragma unroll
+            for (int tyx = 0; tyx < 16; ++tyx) {
+                const f32x4 f0 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8);
+                const f32x4 f1 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8 + 4);
+                acc[0] = __builtin_fmaf(v[tyx], f0.x, acc[0]); acc[1] = __builtin_fmaf(v[tyx], f0.y, acc[1]);
+                acc[2] = __builtin_fmaf(v[tyx], f0.z, acc[2]); acc[3] = __builtin_fmaf(v[tyx], f0.w, acc[3]);
+                acc[4] = __builtin_fmaf(v[tyx], f1.x, acc[4]); acc[5] = __builtin_fmaf(v[tyx], f1.y, acc[5]);
+                acc[6] = __builtin_fmaf(v[tyx], f1.z, acc[6]); acc[7] = __builtin_fmaf(v[tyx], f1.w, acc[7]);
+            }
+        }
+        if (valid) {
+            const long long ol = (long long)c * dvol + cc;
+            if (a.d_mul_l) dm[0] = __builtin_fmaf(acc[0], a.lll[ol], dm[0]);
+            a.d_lll[ol] = a.mul_l ? acc[0] * m[0] : acc[0];
+#pragma unroll
+            for (int s = 1; s < 8; ++s) {
+                const long long oh = ((long long)c * 7 + (s - 1)) * dvol + cc;
+                if (a.d_mul_h) dm[s] = __builtin_fmaf(acc[s], a.hf[oh], dm[s]);
+                a.d_hf[oh] = a.mul_h ? acc[s] * m[s] : acc[s];
+            }
+        }
+    }
+    if (slot > 0) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) s_red[slot - 1][s][lane] = dm[s];
+    }
+    __syncthreads();
+    if (slot == 0 && valid) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float t = (dm[s] + s_red[0][s][lane]) + (s_red[1][s][lane] + s_red[2][s][lane]);
+            if (s == 0) { if (a.d_mul_l) a.d_mul_l[cc] = t; }
+            else if (a.d_mul_h) a.d_mul_h[(long long)(s - 1) * dvol + cc] = t;
+        }
+    }
+}
+
 // (C, V) <-> (V, Cs) through a 32(channel) x 64(voxel) LDS tile: both sides move whole 128/256-byte rows.
 __global__ __launch_bounds__(256) void first_to_last_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                             int C, long long V, int cs) {
@@ -208,7 +320,27 @@ extern "C" int lfgc_idwt_level_f32(const float* lll, const float* hf, const floa
     a.C = C; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.t0 = t0; a.t1 = t1; a.t2 = t2;
     a.o0 = (2 * d0 + 2 - t0) / 2; a.o1 = (2 * d1 + 2 - t1) / 2; a.o2 = (2 * d2 + 2 - t2) / 2;
     const long long total = (long long)C * (d0 + 1) * (d1 + 1) * (d2 + 1);
-    hipLaunchKernelGGL(idwt_level_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+    a.mul_l = nullptr; a.mul_h = nullptr; a.thr_l = a.thr_h = 0.0f;
+    hipLaunchKernelGGL(idwt_level_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_idwt_level_drop_f32(const float* lll, const float* hf, const float* mul_lll, float thr_lll,
+                                        const float* mul_hf, float thr_hf, const float* filter_rev, float* out,
+                                        int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream) {
+    const int rc = check_level(lll, hf, filter_rev, out, C, d0, d1, d2, t0, t1, t2);
+    if (rc != LFGC_OK) return rc;
+    IdwtArgs a;
+    a.lll = lll; a.hf = hf; a.filt = filter_rev; a.out = out;
+    a.C = C; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.t0 = t0; a.t1 = t1; a.t2 = t2;
+    a.o0 = (2 * d0 + 2 - t0) / 2; a.o1 = (2 * d1 + 2 - t1) / 2; a.o2 = (2 * d2 + 2 - t2) / 2;
+    a.mul_l = mul_lll; a.mul_h = mul_hf; a.thr_l = thr_lll; a.thr_h = thr_hf;
+    const long long total = (long long)C * (d0 + 1) * (d1 + 1) * (d2 + 1);
+    if (mul_lll || mul_hf)
+        hipLaunchKernelGGL(idwt_level_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(idwt_level_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }
@@ -225,6 +357,25 @@ extern "C" int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_r
     a.lo0 = (2 * d0 + 2 - t0) / 2; a.lo1 = (2 * d1 + 2 - t1) / 2; a.lo2 = (2 * d2 + 2 - t2) / 2;
     a.d0 = d0; a.d1 = d1; a.d2 = d2;
     hipLaunchKernelGGL(analysis_kernel, dim3(grid_for((long long)C * dvol)), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* lll, const float* hf,
+                                            const float* mul_lll, const float* mul_hf, float* d_lll, float* d_hf,
+                                            float* d_mul_lll, float* d_mul_hf, int C, int d0, int d1, int d2,
+                                            int t0, int t1, int t2, lfgc_stream_t stream) {
+    const int rc = check_level(d_out, filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
+    if (rc != LFGC_OK) return rc;
+    if ((d_mul_lll && (!mul_lll || !lll)) || (d_mul_hf && (!mul_hf || !hf))) return LFGC_E_NULL;
+    AdjointDropArgs a;
+    a.src = d_out; a.filt = filter_rev; a.lll = lll; a.hf = hf; a.mul_l = mul_lll; a.mul_h = mul_hf;
+    a.d_lll = d_lll; a.d_hf = d_hf; a.d_mul_l = d_mul_lll; a.d_mul_h = d_mul_hf;
+    a.C = C; a.n0 = t0; a.n1 = t1; a.n2 = t2;
+    a.lo0 = (2 * d0 + 2 - t0) / 2; a.lo1 = (2 * d1 + 2 - t1) / 2; a.lo2 = (2 * d2 + 2 - t2) / 2;
+    a.d0 = d0; a.d1 = d1; a.d2 = d2;
+    const long long dvol = (long long)d0 * d1 * d2;
+    hipLaunchKernelGGL(adjoint_drop_kernel, dim3(grid_for(dvol, 64)), dim3(256), 0, (hipStream_t)stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }

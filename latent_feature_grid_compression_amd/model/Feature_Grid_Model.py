@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..wavelet_transform.Torch_Wavelet_Transform import _WaveletFilterNd, dwt_max_level
+from .Dropout_Layer import DropoutLayer
 from .Feature_Embedding import Embedder
 
 
@@ -91,6 +92,38 @@ class Feature_Grid_Model(nn.Module):
     def _identity_drop(self) -> bool:
         return all(isinstance(d, nn.Identity) for d in self.drop)
 
+    def _dropped(self):
+        """Coefficient tensors with their drop layers resolved (reference :103, :105): this package's layers only
+        name their per-coefficient factor -- the multiply happens inside the IDWT kernels --, any other module
+        (nn.Identity, a reference DropoutLayer object handed in by the caller) is called as it is."""
+        coeffs, factors, thresholds = [], [], []
+        for g, d in zip(self.feature_grid, self.drop):
+            f = d.drop_factor() if isinstance(d, DropoutLayer) else None
+            if f is None and not isinstance(d, (nn.Identity, DropoutLayer)):
+                g = d(g)
+            coeffs.append(g)
+            factors.append(None if f is None else f.mul)
+            thresholds.append(None if f is None else f.threshold)
+        return coeffs, factors, thresholds
+
+    def _decode(self, channel_last: bool) -> torch.Tensor:
+        coeffs, factors, thresholds = self._dropped()
+        fused = any(f is not None for f in factors)
+        if fused and len(coeffs) == 1:                     # no wavelet level at all: the layer is all there is
+            coeffs = [ops.DropApplyFn.apply(coeffs[0], factors[0], thresholds[0])]
+            fused = False
+        track = torch.is_grad_enabled() and any(t.requires_grad for t in coeffs + [f for f in factors if f is not None])
+        if fused:
+            if track:
+                return ops.DecodeVolumeDropFn.apply(self.filter.filter_rev, self.shape_array, channel_last, thresholds,
+                                                    len(coeffs), *[c.contiguous() for c in coeffs], *factors)
+            return ops.decode_levels_drop([c.detach() for c in coeffs], [None if f is None else f.detach() for f in factors],
+                                          thresholds, self.shape_array, self.filter.filter_rev, channel_last)
+        if track:
+            return ops.DecodeVolumeFn.apply(self.filter.filter_rev, self.shape_array, channel_last,
+                                            *[c.contiguous() for c in coeffs])
+        return ops.decode_levels(coeffs, self.shape_array, self.filter.filter_rev, channel_last=channel_last)
+
     def _decoded_channel_last(self) -> torch.Tensor:
         """decode_volume() in the sampler's layout (G,G,G,Cs).  Differentiable when grads are enabled;
         cached across calls in no-grad mode while no coefficient changed (the reference re-decodes the
@@ -100,12 +133,7 @@ class Feature_Grid_Model(nn.Module):
         key = self._key(list(self.feature_grid) + [self.filter.filter_rev]) if cacheable else None
         if cacheable and self._grid_cache is not None and self._grid_cache[0] == key:
             return self._grid_cache[1]
-        coeffs = [d(g) for g, d in zip(self.feature_grid, self.drop)]
-        if track or any(c.requires_grad for c in coeffs):
-            grid = ops.DecodeVolumeFn.apply(self.filter.filter_rev, self.shape_array, True,
-                                            *[c.contiguous() for c in coeffs])
-        else:
-            grid = ops.decode_levels(coeffs, self.shape_array, self.filter.filter_rev, channel_last=True)
+        grid = self._decode(channel_last=True)
         if cacheable:
             self._grid_cache = (key, grid)
         return grid
@@ -146,10 +174,7 @@ class Feature_Grid_Model(nn.Module):
 
     def decode_volume(self) -> torch.Tensor:
         """Dense grid (C,G,G,G), channel-first like the reference's decode_volume()."""
-        coeffs = [d(g).contiguous() for g, d in zip(self.feature_grid, self.drop)]
-        if torch.is_grad_enabled() and any(c.requires_grad for c in coeffs):
-            return ops.DecodeVolumeFn.apply(self.filter.filter_rev, self.shape_array, False, *coeffs)
-        return ops.decode_levels(coeffs, self.shape_array, self.filter.filter_rev, channel_last=False)
+        return self._decode(channel_last=False)
 
     # ---- pruning bookkeeping (reference :110-140): pure tensor logic on the drop layers' own methods ------
     def save_dropvalues_on_grid(self, device):

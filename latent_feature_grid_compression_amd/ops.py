@@ -150,6 +150,214 @@ class DecodeVolumeFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+# ---- pruning ("drop") layers fused into the decode --------------------------------
+
+_NAN = float('nan')
+
+
+def _thr(v) -> float:
+    return _NAN if v is None else float(v)
+
+
+def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> torch.Tensor:
+    """One IDWT level with the drop factors of its inputs folded in: mul_l (d0,d1,d2) / mul_h (7,d0,d1,d2) or None;
+    thr None = plain product, a float = masked straight-through rule (see include/lfgc.h)."""
+    _require_hip(lll, hf, filter_rev, mul_l, mul_h)
+    lll, hf, filter_rev = _f32c(lll), _f32c(hf), _f32c(filter_rev)
+    C, d0, d1, d2 = lll.shape
+    if tuple(hf.shape) != (C, 7, d0, d1, d2):
+        raise ValueError('detail bands %s do not match low band %s' % (tuple(hf.shape), tuple(lll.shape)))
+    if mul_l is not None:
+        mul_l = _f32c(mul_l)
+        if tuple(mul_l.shape) != (d0, d1, d2):
+            raise ValueError('low-band drop factor %s does not match %s' % (tuple(mul_l.shape), (d0, d1, d2)))
+    if mul_h is not None:
+        mul_h = _f32c(mul_h)
+        if tuple(mul_h.shape) != (7, d0, d1, d2):
+            raise ValueError('detail drop factor %s does not match %s' % (tuple(mul_h.shape), (7, d0, d1, d2)))
+    t = [int(v) for v in target]
+    out = torch.empty((C, t[0], t[1], t[2]), dtype=torch.float32, device=lll.device)
+    check(_lib.load().lfgc_idwt_level_drop_f32(
+        lll.data_ptr(), hf.data_ptr(), mul_l.data_ptr() if mul_l is not None else None, _thr(thr_l),
+        mul_h.data_ptr() if mul_h is not None else None, _thr(thr_h), filter_rev.data_ptr(), out.data_ptr(),
+        C, d0, d1, d2, t[0], t[1], t[2], _stream(lll)), 'lfgc_idwt_level_drop_f32')
+    return out
+
+
+def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml: bool, want_dmh: bool, d):
+    """Adjoint of idwt_level_drop -> (d_lll, d_hf, d_mul_l or None, d_mul_h or None)."""
+    _require_hip(d_out, filter_rev)
+    d_out, filter_rev = _f32c(d_out), _f32c(filter_rev)
+    C, t0, t1, t2 = d_out.shape
+    d = [int(v) for v in d]
+    dev = d_out.device
+    d_lll = torch.empty((C, d[0], d[1], d[2]), dtype=torch.float32, device=dev)
+    d_hf = torch.empty((C, 7, d[0], d[1], d[2]), dtype=torch.float32, device=dev)
+    d_ml = torch.empty((d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dml else None
+    d_mh = torch.empty((7, d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dmh else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    check(_lib.load().lfgc_idwt_level_drop_bwd_f32(
+        d_out.data_ptr(), filter_rev.data_ptr(), ptr(lll), ptr(hf), ptr(mul_l), ptr(mul_h), d_lll.data_ptr(),
+        d_hf.data_ptr(), ptr(d_ml), ptr(d_mh), C, d[0], d[1], d[2], t0, t1, t2, _stream(d_out)),
+        'lfgc_idwt_level_drop_bwd_f32')
+    return d_lll, d_hf, d_ml, d_mh
+
+
+def drop_apply(x: torch.Tensor, mul: torch.Tensor, thr=None) -> torch.Tensor:
+    """x (C, ...) * mul (...) with the value rule of include/lfgc.h (one drop layer outside the decode)."""
+    _require_hip(x, mul)
+    x, mul = _f32c(x), _f32c(mul)
+    if tuple(x.shape[1:]) != tuple(mul.shape):
+        raise ValueError('drop factor %s does not match coefficients %s' % (tuple(mul.shape), tuple(x.shape)))
+    out = torch.empty_like(x)
+    check(_lib.load().lfgc_drop_apply_f32(x.data_ptr(), mul.data_ptr(), _thr(thr), out.data_ptr(), x.shape[0],
+                                          mul.numel(), _stream(x)), 'lfgc_drop_apply_f32')
+    return out
+
+
+class DropApplyFn(torch.autograd.Function):
+    """A drop layer's own forward(x): value by the layer's rule, gradients d_x = g*m, d_m = sum_c g*x."""
+
+    @staticmethod
+    def forward(ctx, x, mul, thr):
+        ctx.save_for_backward(x.detach(), mul.detach())
+        ctx.need_dm = mul.requires_grad
+        return drop_apply(x.detach(), mul.detach(), thr)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mul = ctx.saved_tensors
+        g, x, mul = _f32c(g), _f32c(x), _f32c(mul)
+        d_x = torch.empty_like(x)
+        d_m = torch.empty_like(mul) if ctx.need_dm else None
+        check(_lib.load().lfgc_drop_apply_bwd_f32(g.data_ptr(), x.data_ptr(), mul.data_ptr(), d_x.data_ptr(),
+                                                  d_m.data_ptr() if d_m is not None else None, x.shape[0], mul.numel(),
+                                                  _stream(g)), 'lfgc_drop_apply_bwd_f32')
+        return d_x, d_m, None
+
+
+def decode_levels_drop(coeffs, factors, thresholds, shape_array, filter_rev, channel_last: bool) -> torch.Tensor:
+    """decode_volume() with drop factors (model/Feature_Grid_Model.py:102-108): factors[i] / thresholds[i] belong
+    to coeffs[i]; None = that tensor passes unchanged."""
+    if len(coeffs) == 1:
+        restored = coeffs[0] if factors[0] is None else drop_apply(coeffs[0], factors[0], thresholds[0])
+    else:
+        restored, mul_l, thr_l = coeffs[0], factors[0], thresholds[0]
+        for k in range(1, len(coeffs)):
+            restored = idwt_level_drop(restored, coeffs[k], mul_l, thr_l, factors[k], thresholds[k], filter_rev,
+                                       shape_array[k - 1])
+            mul_l, thr_l = None, None
+    return to_channel_last(restored) if channel_last else restored
+
+
+class DecodeVolumeDropFn(torch.autograd.Function):
+    """decode_volume() with the drop layers folded into the IDWT kernels, as one autograd node.
+    apply(filter_rev, shape_array, channel_last, thresholds, n, *coeffs, *factors) -- n coefficient tensors, then n
+    factors (tensor or None); needs at least one wavelet level."""
+
+    @staticmethod
+    def forward(ctx, filter_rev, shape_array, channel_last, thresholds, n, *tensors):
+        coeffs, factors = tensors[:n], tensors[n:]
+        ctx.filter_rev = filter_rev
+        ctx.shape_array = [tuple(int(v) for v in s) for s in shape_array]
+        ctx.channel_last = bool(channel_last)
+        ctx.n = n
+        ctx.dims = [tuple(c.shape) for c in coeffs]
+        ctx.want = [f is not None and f.requires_grad for f in factors]
+        ctx.has = [f is not None for f in factors]
+        det = [c.detach() for c in coeffs]
+        fdet = [f.detach() if f is not None else None for f in factors]
+        ctx.save_for_backward(*det, *[f for f in fdet if f is not None])
+        with torch.no_grad():
+            return decode_levels_drop(det, fdet, list(thresholds), ctx.shape_array, filter_rev, ctx.channel_last)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n = ctx.n
+        saved = list(ctx.saved_tensors)
+        coeffs = saved[:n]
+        it = iter(saved[n:])
+        factors = [next(it) if h else None for h in ctx.has]
+        C = ctx.dims[0][0]
+        g = to_channel_first(d_out, C) if ctx.channel_last else d_out
+        d_coef, d_fac = [None] * n, [None] * n
+        for lvl in range(n - 1, 0, -1):
+            first = lvl == 1
+            ml = factors[0] if first else None
+            g, d_hf, d_ml, d_mh = idwt_level_drop_bwd(
+                g, ctx.filter_rev, coeffs[0] if first else None, coeffs[lvl], ml, factors[lvl],
+                first and ctx.want[0], ctx.want[lvl], ctx.dims[lvl][2:])
+            d_coef[lvl], d_fac[lvl] = d_hf, d_mh
+            if first:
+                d_fac[0] = d_ml
+        d_coef[0] = g
+        return (None, None, None, None, None) + tuple(d_coef) + tuple(d_fac)
+
+
+def sign_variance_update(betas: torch.Tensor, ema: torch.Tensor, emavar: torch.Tensor, momentum: float) -> None:
+    """In-place EMA / EMA-variance step of the Smallify sign tracker (model/Smallify_Dropout.py:106-112)."""
+    _require_hip(betas, ema, emavar)
+    if not (ema.is_contiguous() and emavar.is_contiguous() and ema.dtype == emavar.dtype == torch.float32):
+        raise ValueError('tracker state must be contiguous fp32')
+    b = _f32c(betas.detach())
+    check(_lib.load().lfgc_sign_variance_update_f32(b.data_ptr(), ema.data_ptr(), emavar.data_ptr(), float(momentum),
+                                                    b.numel(), _stream(b)), 'lfgc_sign_variance_update_f32')
+
+
+def _penalty_terms(kinds, tensors):
+    if len(kinds) > _lib.PENALTY_MAX_TERMS:
+        raise ValueError('at most %d penalty terms per launch' % _lib.PENALTY_MAX_TERMS)
+    terms = (_lib.PenaltyTerm * len(kinds))()
+    keep, it = [], iter(tensors)
+    for t, kind in enumerate(kinds):
+        a = _f32c(next(it).detach())
+        b = _f32c(next(it).detach()) if kind == _lib.PENALTY_DKL else None
+        _require_hip(a, b)
+        if b is not None and b.shape != a.shape:
+            raise ValueError('log_thetas / log_var shapes differ')
+        keep.append((a, b))
+        terms[t].a, terms[t].b, terms[t].n, terms[t].kind = a.data_ptr(), (b.data_ptr() if b is not None else None), a.numel(), kind
+    return terms, keep
+
+
+class PenaltyFn(torch.autograd.Function):
+    """All penalty terms of a pruning loss in one reduction launch (+ one gradient launch).
+    apply(kinds, *tensors) -> fp32 (len(kinds),); a DKL term consumes two tensors (log_thetas, log_var)."""
+
+    @staticmethod
+    def forward(ctx, kinds, *tensors):
+        kinds = [int(k) for k in kinds]
+        terms, keep = _penalty_terms(kinds, tensors)
+        dev = keep[0][0].device
+        sums = torch.empty(len(kinds), dtype=torch.float64, device=dev)
+        check(_lib.load().lfgc_penalty_sums_f32(terms, len(kinds), sums.data_ptr(), _stream(sums)), 'lfgc_penalty_sums_f32')
+        ctx.kinds = kinds
+        ctx.save_for_backward(*[t.detach() for t in tensors])
+        return sums.float()
+
+    @staticmethod
+    def backward(ctx, d_sums):
+        tensors = ctx.saved_tensors
+        terms, keep = _penalty_terms(ctx.kinds, tensors)
+        d_sums = _f32c(d_sums)
+        ga = [torch.empty_like(a) for a, _ in keep]
+        gb = [torch.empty_like(b) if b is not None else None for _, b in keep]
+        pa, _k1 = _lib.ptr_array([g.data_ptr() for g in ga])
+        pb, _k2 = _lib.ptr_array([g.data_ptr() if g is not None else 0 for g in gb])
+        check(_lib.load().lfgc_penalty_grads_f32(terms, len(ctx.kinds), d_sums.data_ptr(), pa, pb, _stream(d_sums)),
+              'lfgc_penalty_grads_f32')
+        flat = []
+        for g_a, g_b in zip(ga, gb):
+            flat.append(g_a)
+            if g_b is not None:
+                flat.append(g_b)
+        return (None,) + tuple(g.view(t.shape) for g, t in zip(flat, tensors))
+
+
+def penalty_sums(kinds, tensors) -> torch.Tensor:
+    return PenaltyFn.apply(list(kinds), *tensors)
+
+
 # ---- fused sample + embed + MLP ------------------------------------------------------------------------
 
 def pack_mlp(desc: MlpDesc, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
