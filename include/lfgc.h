@@ -53,15 +53,20 @@ const char* lfgc_error_string(int code);
  *   lll        device (C, d0,d1,d2)           low band (coarse parameter or previous level's output)
  *   hf         device (C, 7, d0,d1,d2)        detail bands, sub-band s = 4a+2b+c stored at hf[:, s-1]
  *   filter_rev device (8, 4,4,4)              the module's `filter.filter_rev` buffer (fp32)
+ *   taps       host float[8] or NULL          the 1-D bank [low taps | high taps] (pywt rec_lo, rec_hi cast to fp32) IF
+ *                                             filter_rev is its outer product a[sz][tz]*(a[sy][ty]*a[sx][tx]), the only way the
+ *                                             reference builds it (Torch_Wavelet_Transform.py:39-57): the stencil is then
+ *                                             contracted axis by axis (224 instead of 512 FMAs per 8 outputs; results equal
+ *                                             the dense form up to fp32 rounding) and filter_rev may be NULL
  *   out        device (C, t0,t1,t2)
- * Requires 2*d_a + 2 >= t_a >= 1. */
-int lfgc_idwt_level_f32(const float* lll, const float* hf, const float* filter_rev, float* out,
+ * Requires 2*d_a + 2 >= t_a >= 1.  The same `taps` convention applies to every wavelet entry point below. */
+int lfgc_idwt_level_f32(const float* lll, const float* hf, const float* filter_rev, const float* taps, float* out,
                         int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
 
 /* Adjoint of lfgc_idwt_level_f32 (what autograd derives for the ops above; triggered at
  * training/training.py:137): d_lll (C,d0,d1,d2) and d_hf (C,7,d0,d1,d2) are OVERWRITTEN with the
  * gradients given d_out (C, t0,t1,t2). */
-int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_rev, float* d_lll, float* d_hf,
+int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_rev, const float* taps, float* d_lll, float* d_hf,
                             int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
 
 /* Layout conversion of a dense grid between the reference's channel-first (C, V) = decode_volume()'s output
@@ -75,8 +80,9 @@ int lfgc_grid_layout_f32(const float* src, float* dst, int C, int64_t voxels, in
  * (wavelet_transform/Torch_Wavelet_Transform.py:59-67, :75-89): zero-pad (2, 2 + odd) per axis,
  * grouped conv3d stride 2.  in (C, n0,n1,n2) -> out (C, 8, d0,d1,d2), d_a = (n_a + pad_hi_a) / 2 + 1 - ...
  * exactly: d_a = (n_a + 2 + 2 + odd_a' - 4) / 2 + 1 where odd_a' is the reference's pad-slot quirk
- * (the odd bit of axis a lands on axis 2-a).  filter_fwd device (8,4,4,4). */
-int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, float* out,
+ * (the odd bit of axis a lands on axis 2-a).  filter_fwd device (8,4,4,4); taps = its 1-D bank (pywt dec_lo, dec_hi,
+ * each flipped) or NULL. */
+int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, const float* taps, float* out,
                        int C, int n0, int n1, int n2, lfgc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -97,12 +103,12 @@ int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, float* out,
  *   mul_lll device (d0,d1,d2) or NULL     factor of the low band (only the coarsest level has one: drop[0])
  *   mul_hf  device (7, d0,d1,d2) or NULL  factor of the detail bands (drop[level]) */
 int lfgc_idwt_level_drop_f32(const float* lll, const float* hf, const float* mul_lll, float threshold_lll,
-                             const float* mul_hf, float threshold_hf, const float* filter_rev, float* out,
+                             const float* mul_hf, float threshold_hf, const float* filter_rev, const float* taps, float* out,
                              int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
 
 /* Adjoint of lfgc_idwt_level_drop_f32: d_lll / d_hf are the gradients of the UN-multiplied inputs;
  * d_mul_lll (d0,d1,d2) / d_mul_hf (7,d0,d1,d2) receive the factor gradients (NULL = not wanted; needs lll / hf). */
-int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* lll, const float* hf,
+int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* taps, const float* lll, const float* hf,
                                  const float* mul_lll, const float* mul_hf, float* d_lll, float* d_hf,
                                  float* d_mul_lll, float* d_mul_hf, int C, int d0, int d1, int d2,
                                  int t0, int t1, int t2, lfgc_stream_t stream);

@@ -33,18 +33,19 @@ class PenaltyTerm(Structure):
 PENALTY_L1, PENALTY_L2, PENALTY_DKL = 0, 1, 2
 PENALTY_MAX_TERMS = 16
 _PP = POINTER(c_void_p)
+_TAPS = POINTER(c_float)          # host float[8] (1-D filter bank) or None
 
 # name -> (restype, argtypes); mirrors include/lfgc.h one to one
 SIGNATURES = {
     'lfgc_version': (c_int, []),
     'lfgc_error_string': (c_char_p, [c_int]),
-    'lfgc_idwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
-    'lfgc_idwt_level_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'lfgc_idwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, _TAPS, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'lfgc_idwt_level_bwd_f32': (c_int, [c_void_p, c_void_p, _TAPS, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'lfgc_grid_layout_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
-    'lfgc_dwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    'lfgc_idwt_level_drop_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, c_void_p] +
+    'lfgc_dwt_level_f32': (c_int, [c_void_p, c_void_p, _TAPS, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'lfgc_idwt_level_drop_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, _TAPS, c_void_p] +
                                  [c_int] * 7 + [c_void_p]),
-    'lfgc_idwt_level_drop_bwd_f32': (c_int, [c_void_p] * 10 + [c_int] * 7 + [c_void_p]),
+    'lfgc_idwt_level_drop_bwd_f32': (c_int, [c_void_p, c_void_p, _TAPS] + [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
     'lfgc_drop_apply_f32': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_void_p]),
     'lfgc_drop_apply_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'lfgc_sign_variance_update_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),

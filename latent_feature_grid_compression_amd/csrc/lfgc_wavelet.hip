@@ -1,13 +1,16 @@
 // lfgc_wavelet.hip -- 4-tap (db2) separable-bank 3-D wavelet kernels for gfx950.
-//   lfgc_idwt_level_f32      replaces wavelet_transform/Torch_Wavelet_Transform.py:91-104 (+ crop :69-73)
-//   lfgc_idwt_level_bwd_f32  its adjoint (autograd of the same lines)
-//   lfgc_dwt_level_f32       replaces :59-67, :75-89 (init-time encode)
-//   lfgc_grid_layout_f32     channel-first <-> channel-last conversion of the dense grid (the sampler and the
-//                            gradient scatter work channel-last, the stencils channel-first)
-// All of them are HBM/L2-bound byte movers (no contraction worth an MFMA).  Both stencils use the same shape:
-// one thread owns one coarse cell of one channel, issues its 64 loads up front (predicated by clamped index and a
-// zeroing select, never by a branch, so they are all in flight together), then forms 8 results with 64 FMAs each
-// against filter taps that are wave-uniform scalar loads; lanes run along the last spatial axis.
+//   lfgc_idwt_level_f32           replaces wavelet_transform/Torch_Wavelet_Transform.py:91-104 (+ crop :69-73)
+//   lfgc_idwt_level_bwd_f32       its adjoint (autograd of the same lines)
+//   lfgc_idwt_level_drop_f32/_bwd the same two with the pruning layers' per-coefficient factors folded in
+//   lfgc_dwt_level_f32            replaces :59-67, :75-89 (init-time encode)
+//   lfgc_grid_layout_f32          channel-first <-> channel-last conversion of the dense grid (the sampler and the
+//                                 gradient scatter work channel-last, the stencils channel-first)
+// All of them are byte movers with a 64-FMA-per-output stencil (no contraction worth an MFMA).  Both stencils share
+// one shape: a workgroup owns 2 z-slices x 128 consecutive cells of the flattened (y,x) plane of ONE channel, copies
+// the input neighbourhood of those cells into LDS as plain contiguous chunks of the source rows (every source value
+// is fetched from memory once per workgroup instead of once per reading thread: the per-thread version was bound by
+// the 64 vector-load instructions each thread issued), then every thread forms its 8 results from LDS with filter
+// taps that are broadcast LDS reads.  Boundary handling is a select on the LDS value, never a branch.
 #include "lfgc_common.h"
 
 namespace {
@@ -18,6 +21,8 @@ struct IdwtArgs {
     const float* filt;  // (8,4,4,4)
     float* out;         // (C, t0,t1,t2)
     int C, d0, d1, d2, t0, t1, t2, o0, o1, o2;   // o = crop offset floor((2d+2-t)/2)
+    int len;            // plane offsets per staged z-plane (multiple of 256)
+    float taps[8];      // SEP build: the 1-D bank the filter is the outer product of: [low | high][tap]
     // DROP build only: the pruning layers' per-coefficient factors, shared by all channels
     const float* mul_l; // (d0,d1,d2) or NULL
     const float* mul_h; // (7, d0,d1,d2) or NULL
@@ -33,46 +38,136 @@ __device__ __forceinline__ float drop_value(float x, float m, float thr, bool st
     return __fadd_rn(__fsub_rn(__fmul_rn(x, hard), soft), soft);
 }
 
+constexpr int kTileCells = 128;      // cells of the flattened (y,x) plane per z-slice of a workgroup
+
 // Synthesis: out_full[o] = sum_{s,t} in[s][i] F_s[t], o = 2 i + t per axis.  Thread = cell jj in [0,d] per axis:
 // it produces the 2x2x2 outputs o = 2 jj + p from the cells i = jj - e (e in {0,1}) with taps t = p + 2 e.
-template <bool DROP>
+// LDS: [512 filter taps as [tap][band]] [3 z-planes (jz0 - 1 + zl)][len plane offsets][12 floats: the 8 bands of that
+// cell + pad]; element k is plane offset chunk0 + k, chunk0 = (first cell row - 1) * d2 - 1.  The 48-byte records make
+// both the two ds_write_b128 of the staging and the two ds_read_b128 per neighbour cell conflict-free (stride 4 * 3
+// dwords).  Offsets outside the plane (and z-planes outside the level) are staged as zeros, so only the x range of a
+// neighbour needs a select.  `len` is a multiple of 256: one record per thread per staging pass.
+constexpr int kRec = 12;
+
+template <bool DROP, bool SEP>
 __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
-    // filter bank re-laid [tap][band] in LDS: the 8 bands of one tap are two broadcast ds_read_b128
-    // (left in global memory hipcc fetches every tap with a per-lane vector load: 512 extra loads per thread)
-    __shared__ __attribute__((aligned(16))) float s_f[512];
-    for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
-    __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_f = s_dyn;
+    float* s_v = s_dyn + 512;
+    if (!SEP)
+        for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
     const int n0 = a.d0 + 1, n1 = a.d1 + 1, n2 = a.d2 + 1;
-    const long long total = (long long)a.C * n0 * n1 * n2;
-    const long long dvol = (long long)a.d0 * a.d1 * a.d2;
-    // one cell per thread, no grid-stride loop: a loop makes the LDS filter reads loop-invariant and hipcc then
-    // hoists all 512 taps into VGPRs (256 VGPRs + scratch, occupancy 1)
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx < total) {
-        const int jx = (int)(idx % n2);
-        long long r = idx / n2;
-        const int jy = (int)(r % n1); r /= n1;
-        const int jz = (int)(r % n0);
-        const int c = (int)(r / n0);
-        const float* in_l = a.lll + (long long)c * dvol;
-        const float* in_h = a.hf + (long long)c * 7 * dvol;
-        float v[8][8];                                       // [e = ez*4+ey*2+ex][band]
+    const int plane_cells = n1 * n2;
+    const int tiles = (plane_cells + kTileCells - 1) / kTileCells, ztiles = (n0 + 1) / 2;
+    int b = blockIdx.x;
+    const int pt = b % tiles; b /= tiles;
+    const int zt = b % ztiles;
+    const int c = b / ztiles;
+    const int f0 = pt * kTileCells, jz0 = zt * 2;
+    const int chunk0 = (f0 / n2 - 1) * a.d2 - 1;
+    const int len = a.len;
+    const int dplane = a.d1 * a.d2;
+    const int dvol = dplane * a.d0;                       // < 2^31 / 8 (checked on the host)
+    const float* lc = a.lll + (long long)c * dvol;
+    const float* hc = a.hf + (long long)c * 7 * dvol;
+#pragma unroll 1
+    for (int kk = threadIdx.x; kk < len; kk += 256) {
+        const int off = chunk0 + kk;
+        const bool in_plane = off >= 0 && off < dplane;
+        float r[3][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int iz = jz - (e >> 2), iy = jy - ((e >> 1) & 1), ix = jx - (e & 1);
-            const bool ok = iz >= 0 && iz < a.d0 && iy >= 0 && iy < a.d1 && ix >= 0 && ix < a.d2;
-            const long long sp = ((long long)min(max(iz, 0), a.d0 - 1) * a.d1 + min(max(iy, 0), a.d1 - 1)) * a.d2 +
-                                 min(max(ix, 0), a.d2 - 1);
-            float l = in_l[sp];
-            if (DROP && a.mul_l) l = drop_value(l, a.mul_l[sp], a.thr_l, a.thr_l == a.thr_l);
-            v[e][0] = ok ? l : 0.0f;
+        for (int zl = 0; zl < 3; ++zl) {
+            const int iz = jz0 - 1 + zl;
+            const bool ok = in_plane && iz >= 0 && iz < a.d0;
+            const int o = ok ? iz * dplane + off : 0;
+            r[zl][0] = lc[o];
 #pragma unroll
-            for (int s = 1; s < 8; ++s) {
-                float h = in_h[(long long)(s - 1) * dvol + sp];
-                if (DROP && a.mul_h) h = drop_value(h, a.mul_h[(long long)(s - 1) * dvol + sp], a.thr_h, a.thr_h == a.thr_h);
-                v[e][s] = ok ? h : 0.0f;
+            for (int sb = 1; sb < 8; ++sb) r[zl][sb] = hc[(sb - 1) * dvol + o];
+            if (DROP) {
+                if (a.mul_l) r[zl][0] = drop_value(r[zl][0], a.mul_l[o], a.thr_l, a.thr_l == a.thr_l);
+                if (a.mul_h) {
+#pragma unroll
+                    for (int sb = 1; sb < 8; ++sb)
+                        r[zl][sb] = drop_value(r[zl][sb], a.mul_h[(sb - 1) * dvol + o], a.thr_h, a.thr_h == a.thr_h);
+                }
+            }
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) r[zl][sb] = ok ? r[zl][sb] : 0.0f;
+        }
+#pragma unroll
+        for (int zl = 0; zl < 3; ++zl) {
+            float* rec = s_v + (zl * len + kk) * kRec;
+            *reinterpret_cast<f32x4*>(rec) = f32x4{r[zl][0], r[zl][1], r[zl][2], r[zl][3]};
+            *reinterpret_cast<f32x4*>(rec + 4) = f32x4{r[zl][4], r[zl][5], r[zl][6], r[zl][7]};
+        }
+    }
+    __syncthreads();
+    const int zl_t = threadIdx.x >> 7;
+    const int f = f0 + (threadIdx.x & (kTileCells - 1));
+    const int jz = jz0 + zl_t;
+    const bool valid = f < plane_cells && jz < n0;
+    const int fc = min(f, plane_cells - 1);
+    const int jy = fc / n2, jx = fc - jy * n2;
+    const int k00 = jy * a.d2 + jx - chunk0;
+    float v[8][8];                                       // [e = ez*4+ey*2+ex][band]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
+        const bool xok = ex ? jx >= 1 : jx < a.d2;
+        const float* rec = s_v + ((zl_t + 1 - ez) * len + k00 - ey * a.d2 - ex) * kRec;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(rec);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(rec + 4);
+        v[e][0] = xok ? lo.x : 0.0f; v[e][1] = xok ? lo.y : 0.0f; v[e][2] = xok ? lo.z : 0.0f; v[e][3] = xok ? lo.w : 0.0f;
+        v[e][4] = xok ? hi.x : 0.0f; v[e][5] = xok ? hi.y : 0.0f; v[e][6] = xok ? hi.z : 0.0f; v[e][7] = xok ? hi.w : 0.0f;
+    }
+    float* outc = a.out + (long long)c * a.t0 * a.t1 * a.t2;
+    auto store = [&](int p, float val) {
+        const int oz = 2 * jz + (p >> 2) - a.o0, oy = 2 * jy + ((p >> 1) & 1) - a.o1, ox = 2 * jx + (p & 1) - a.o2;
+        if (valid && oz >= 0 && oz < a.t0 && oy >= 0 && oy < a.t1 && ox >= 0 && ox < a.t2)
+            outc[(oz * a.t1 + oy) * a.t2 + ox] = val;
+    };
+    if (SEP) {
+        // F_s[tz][ty][tx] = T[sz][tz] T[sy][ty] T[sx][tx]: contract x, then y, then z in registers (224 FMAs instead
+        // of 512, no filter traffic).  Tap of output parity p and neighbour e along one axis: t = p + 2 e.
+        float X[2][2][2][2][2];                           // [ez][ey][sz][sy][px]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ez = q >> 3, ey = (q >> 2) & 1, sz = (q >> 1) & 1, sy = q & 1;
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                float t = 0.0f;
+#pragma unroll
+                for (int ex = 0; ex < 2; ++ex)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx)
+                        t = __builtin_fmaf(v[ez * 4 + ey * 2 + ex][sz * 4 + sy * 2 + sx], a.taps[sx * 4 + px + 2 * ex], t);
+                X[ez][ey][sz][sy][px] = t;
             }
         }
+        float Y[2][2][2][2];                              // [ez][sz][py][px]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ez = q >> 3, sz = (q >> 2) & 1, py = (q >> 1) & 1, px = q & 1;
+            float t = 0.0f;
+#pragma unroll
+            for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+                for (int sy = 0; sy < 2; ++sy)
+                    t = __builtin_fmaf(X[ez][ey][sz][sy][px], a.taps[sy * 4 + py + 2 * ey], t);
+            Y[ez][sz][py][px] = t;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
+            float t = 0.0f;
+#pragma unroll
+            for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+                for (int sz = 0; sz < 2; ++sz)
+                    t = __builtin_fmaf(Y[ez][sz][py][px], a.taps[sz * 4 + pz + 2 * ez], t);
+            store(p, t);
+        }
+    } else {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
@@ -80,22 +175,24 @@ __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int tap = ((pz + 2 * (e >> 2)) * 4 + (py + 2 * ((e >> 1) & 1))) * 4 + (px + 2 * (e & 1));
-                const f32x4 f0 = *reinterpret_cast<const f32x4*>(s_f + tap * 8);
-                const f32x4 f1 = *reinterpret_cast<const f32x4*>(s_f + tap * 8 + 4);
-                acc = __builtin_fmaf(v[e][0], f0.x, acc); acc = __builtin_fmaf(v[e][1], f0.y, acc);
-                acc = __builtin_fmaf(v[e][2], f0.z, acc); acc = __builtin_fmaf(v[e][3], f0.w, acc);
-                acc = __builtin_fmaf(v[e][4], f1.x, acc); acc = __builtin_fmaf(v[e][5], f1.y, acc);
-                acc = __builtin_fmaf(v[e][6], f1.z, acc); acc = __builtin_fmaf(v[e][7], f1.w, acc);
+                const f32x4 f0v = *reinterpret_cast<const f32x4*>(s_f + tap * 8);
+                const f32x4 f1v = *reinterpret_cast<const f32x4*>(s_f + tap * 8 + 4);
+                acc = __builtin_fmaf(v[e][0], f0v.x, acc); acc = __builtin_fmaf(v[e][1], f0v.y, acc);
+                acc = __builtin_fmaf(v[e][2], f0v.z, acc); acc = __builtin_fmaf(v[e][3], f0v.w, acc);
+                acc = __builtin_fmaf(v[e][4], f1v.x, acc); acc = __builtin_fmaf(v[e][5], f1v.y, acc);
+                acc = __builtin_fmaf(v[e][6], f1v.z, acc); acc = __builtin_fmaf(v[e][7], f1v.w, acc);
             }
-            const int oz = 2 * jz + pz - a.o0, oy = 2 * jy + py - a.o1, ox = 2 * jx + px - a.o2;
-            if (oz >= 0 && oz < a.t0 && oy >= 0 && oy < a.t1 && ox >= 0 && ox < a.t2)
-                a.out[(((long long)c * a.t0 + oz) * a.t1 + oy) * a.t2 + ox] = acc;
+            store(p, acc);          // stored per parity: keeps the filter reads of later parities from being hoisted
         }
     }
 }
 
 // Analysis-form kernel shared by the IDWT adjoint and the forward DWT:
 //   band_s[c][i] = sum_t src_full[c][2 i + t] * F_s[t],  src_full[u] = src[u - lo] (0 outside [0, n))
+// DROP (adjoint with the pruning factors):  stored gradient = band_s * m_s,  d_m_s[i] += band_s[c][i] * coef_s[c][i]
+// (float atomics over the channels: whole 256-byte rows per wave instruction, 8..32 adds per address).
+// LDS: [512 taps] [6 chunks (source z-plane 2 iz0 - lo0 + zl) of `len` floats]; chunk element k is plane offset
+// chunk0 + k, chunk0 = (2 * first cell row - lo1) * n2 - lo2.
 struct AnalysisArgs {
     const float* src;      // (C, n0,n1,n2)
     const float* filt;
@@ -103,149 +200,144 @@ struct AnalysisArgs {
     float* bandh;          // band s>=1 of channel c at bandh + c * cstrideh + (s-1) * dvol
     long long cstride0, cstrideh;
     int C, n0, n1, n2, lo0, lo1, lo2, d0, d1, d2;
-};
-
-__global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_f[512];      // [tap][band], see idwt_level_kernel
-    for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
-    __syncthreads();
-    const long long dvol = (long long)a.d0 * a.d1 * a.d2;
-    const long long nvol = (long long)a.n0 * a.n1 * a.n2;
-    const long long total = (long long)a.C * dvol;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // one cell per thread (see idwt_level_kernel)
-    if (idx < total) {
-        const int ix = (int)(idx % a.d2);
-        long long r = idx / a.d2;
-        const int iy = (int)(r % a.d1); r /= a.d1;
-        const int iz = (int)(r % a.d0);
-        const int c = (int)(r / a.d0);
-        const float* src = a.src + (long long)c * nvol;
-        float acc[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = 0.0f;
-#pragma unroll 1                      // a rolled z-tap loop keeps the live filter taps to one 16-tap plane
-        for (int tz = 0; tz < 4; ++tz) {
-            const int uz = 2 * iz + tz - a.lo0;
-            const bool okz = uz >= 0 && uz < a.n0;
-            const int cz = min(max(uz, 0), a.n0 - 1);
-            float v[16];
-#pragma unroll
-            for (int tyx = 0; tyx < 16; ++tyx) {
-                const int uy = 2 * iy + (tyx >> 2) - a.lo1, ux = 2 * ix + (tyx & 3) - a.lo2;
-                const bool ok = okz && uy >= 0 && uy < a.n1 && ux >= 0 && ux < a.n2;
-                const float x = src[((long long)cz * a.n1 + min(max(uy, 0), a.n1 - 1)) * a.n2 + min(max(ux, 0), a.n2 - 1)];
-                v[tyx] = ok ? x : 0.0f;
-            }
-#pragma unroll
-            for (int tyx = 0; tyx < 16; ++tyx) {
-                const f32x4 f0 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8);
-                const f32x4 f1 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8 + 4);
-                acc[0] = __builtin_fmaf(v[tyx], f0.x, acc[0]); acc[1] = __builtin_fmaf(v[tyx], f0.y, acc[1]);
-                acc[2] = __builtin_fmaf(v[tyx], f0.z, acc[2]); acc[3] = __builtin_fmaf(v[tyx], f0.w, acc[3]);
-                acc[4] = __builtin_fmaf(v[tyx], f1.x, acc[4]); acc[5] = __builtin_fmaf(v[tyx], f1.y, acc[5]);
-                acc[6] = __builtin_fmaf(v[tyx], f1.z, acc[6]); acc[7] = __builtin_fmaf(v[tyx], f1.w, acc[7]);
-            }
-        }
-        const long long sp_out = ((long long)iz * a.d1 + iy) * a.d2 + ix;
-        a.band0[(long long)c * a.cstride0 + sp_out] = acc[0];
-#pragma unroll
-        for (int s = 1; s < 8; ++s) a.bandh[(long long)c * a.cstrideh + (long long)(s - 1) * dvol + sp_out] = acc[s];
-    }
-}
-
-// Adjoint of the IDWT level WITH drop factors (autograd of "coefficients * factor -> conv_transpose3d"):
-//   adj_s[c][i]  = analysis of d_out (as analysis_kernel),   d_coef_s[c][i] = adj_s[c][i] * m_s[i],
-//   d_m_s[i]     = sum_c adj_s[c][i] * coef_s[c][i]          (the factor is shared by all channels).
-// Block = 4 channel slots (one wave each) x 64 cells; a wave walks the channels c = slot, slot+4, ... of its 64 cells,
-// keeps the 8 partial d_m in registers, and the 4 slots are combined through LDS in a fixed order: no atomics, the
-// result is bitwise repeatable.  The channel loop and the z-tap loop stay rolled (see idwt_level_kernel on LICM).
-struct AdjointDropArgs {
-    const float* src;      // d_out (C, n0,n1,n2)
-    const float* filt;
-    const float* lll;      // forward inputs: (C, d0,d1,d2)
-    const float* hf;       //                 (C, 7, d0,d1,d2)
+    int len;
+    float taps[8];         // SEP build: [low | high][tap]
+    // DROP build only
+    const float* lll;      // forward inputs (C, d0,d1,d2), (C, 7, d0,d1,d2): needed for d_mul
+    const float* hf;
     const float* mul_l;    // (d0,d1,d2) or NULL
     const float* mul_h;    // (7, d0,d1,d2) or NULL
-    float* d_lll;          // (C, d0,d1,d2)
-    float* d_hf;           // (C, 7, d0,d1,d2)
-    float* d_mul_l;        // (d0,d1,d2) or NULL
-    float* d_mul_h;        // (7, d0,d1,d2) or NULL
-    int C, n0, n1, n2, lo0, lo1, lo2, d0, d1, d2;
+    float* d_mul_l;        // (d0,d1,d2) or NULL, pre-zeroed
+    float* d_mul_h;        // (7, d0,d1,d2) or NULL, pre-zeroed
 };
 
-__global__ __launch_bounds__(256) void adjoint_drop_kernel(const AdjointDropArgs a) {
-    __shared__ __attribute__((aligned(16))) float s_f[512];      // [tap][band]
-    __shared__ float s_red[3][8][64];                            // partial d_m of slots 1..3
-    for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
+template <bool DROP, bool SEP>
+__global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_f = s_dyn;
+    float* s_v = s_dyn + 512;
+    if (!SEP)
+        for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
+    const int plane_cells = a.d1 * a.d2;
+    const int tiles = (plane_cells + kTileCells - 1) / kTileCells, ztiles = (a.d0 + 1) / 2;
+    int b = blockIdx.x;
+    const int pt = b % tiles; b /= tiles;
+    const int zt = b % ztiles;
+    const int c = b / ztiles;
+    const int f0 = pt * kTileCells, iz0 = zt * 2;
+    const int chunk0 = (2 * (f0 / a.d2) - a.lo1) * a.n2 - a.lo2;
+    const int len = a.len;
+    const int nplane = a.n1 * a.n2;
+    const long long dvol = (long long)plane_cells * a.d0;
+    const float* src = a.src + (long long)c * nplane * a.n0;              // per-channel offsets fit 32 bits (host check)
+#pragma unroll 2
+    for (int kk = threadIdx.x; kk < len; kk += 256) {       // len is a multiple of 256
+        const int off = chunk0 + kk;
+        const bool in_plane = off >= 0 && off < nplane;
+        float r[6];
+#pragma unroll
+        for (int zl = 0; zl < 6; ++zl) {
+            const int uz = 2 * iz0 - a.lo0 + zl;
+            const bool ok = in_plane && uz >= 0 && uz < a.n0;
+            const float x = src[ok ? uz * nplane + off : 0];
+            r[zl] = ok ? x : 0.0f;
+        }
+#pragma unroll
+        for (int zl = 0; zl < 6; ++zl) s_v[zl * len + kk] = r[zl];
+    }
     __syncthreads();
-    const long long dvol = (long long)a.d0 * a.d1 * a.d2;
-    const long long nvol = (long long)a.n0 * a.n1 * a.n2;
-    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
-    const long long cell = (long long)blockIdx.x * 64 + lane;
-    const bool valid = cell < dvol;
-    const long long cc = valid ? cell : dvol - 1;
-    const int ix = (int)(cc % a.d2);
-    const long long r = cc / a.d2;
-    const int iy = (int)(r % a.d1), iz = (int)(r / a.d1);
-    float m[8], dm[8];
-    m[0] = a.mul_l ? a.mul_l[cc] : 1.0f;
+    const int zl_t = threadIdx.x >> 7;
+    const int f = f0 + (threadIdx.x & (kTileCells - 1));
+    const int iz = iz0 + zl_t;
+    const bool valid = f < plane_cells && iz < a.d0;
+    const int fc = min(f, plane_cells - 1);
+    const int iy = fc / a.d2, ix = fc - iy * a.d2;
+    float acc[8];
 #pragma unroll
-    for (int s = 1; s < 8; ++s) m[s] = a.mul_h ? a.mul_h[(long long)(s - 1) * dvol + cc] : 1.0f;
+    for (int s = 0; s < 8; ++s) acc[s] = 0.0f;
+    // every tap of a valid cell lies inside the staged chunk; rows / planes outside the source were staged as zeros,
+    // so only the x range needs a select
+    const int k0 = (2 * iy - a.lo1) * a.n2 + (2 * ix - a.lo2) - chunk0;
+    bool xok[4];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) dm[s] = 0.0f;
-#pragma unroll 1
-    for (int c = slot; c < a.C; c += 4) {
-        const float* src = a.src + (long long)c * nvol;
-        float acc[8];
+    for (int tx = 0; tx < 4; ++tx) { const int ux = 2 * ix + tx - a.lo2; xok[tx] = ux >= 0 && ux < a.n2; }
+    if (SEP) {
+        // contract x, then y, then z (see idwt_level_kernel): band s = 4 sz + 2 sy + sx
+        float Y[4][2][2];                                 // [tz][sy][sx]
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = 0.0f;
-#pragma unroll 1
         for (int tz = 0; tz < 4; ++tz) {
-            const int uz = 2 * iz + tz - a.lo0;
-            const bool okz = uz >= 0 && uz < a.n0;
-            const int cz = min(max(uz, 0), a.n0 - 1);
-            float v[16];
+            const float* pl = s_v + (2 * zl_t + tz) * len + k0;
+            float X[4][2];                                // [ty][sx]
 #pragma unroll
-            for (int tyx = 0; tyx < 16; ++tyx) {
-                const int uy = 2 * iy + (tyx >> 2) - a.lo1, ux = 2 * ix + (tyx & 3) - a.lo2;
-                const bool ok = okz && uy >= 0 && uy < a.n1 && ux >= 0 && ux < a.n2;
-                const float x = src[((long long)cz * a.n1 + min(max(uy, 0), a.n1 - 1)) * a.n2 + min(max(ux, 0), a.n2 - 1)];
-                v[tyx] = ok ? x : 0.0f;
+            for (int ty = 0; ty < 4; ++ty) {
+                const float* row = pl + ty * a.n2;
+                float x0 = 0.0f, x1 = 0.0f;
+#pragma unroll
+                for (int tx = 0; tx < 4; ++tx) {
+                    const float val = xok[tx] ? row[tx] : 0.0f;
+                    x0 = __builtin_fmaf(val, a.taps[tx], x0);
+                    x1 = __builtin_fmaf(val, a.taps[4 + tx], x1);
+                }
+                X[ty][0] = x0; X[ty][1] = x1;
             }
 #pragma unroll
-            for (int tyx = 0; tyx < 16; ++tyx) {
-                const f32x4 f0 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8);
-                const f32x4 f1 = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8 + 4);
-                acc[0] = __builtin_fmaf(v[tyx], f0.x, acc[0]); acc[1] = __builtin_fmaf(v[tyx], f0.y, acc[1]);
-                acc[2] = __builtin_fmaf(v[tyx], f0.z, acc[2]); acc[3] = __builtin_fmaf(v[tyx], f0.w, acc[3]);
-                acc[4] = __builtin_fmaf(v[tyx], f1.x, acc[4]); acc[5] = __builtin_fmaf(v[tyx], f1.y, acc[5]);
-                acc[6] = __builtin_fmaf(v[tyx], f1.z, acc[6]); acc[7] = __builtin_fmaf(v[tyx], f1.w, acc[7]);
-            }
+            for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int ty = 0; ty < 4; ++ty) t = __builtin_fmaf(X[ty][sx], a.taps[sy * 4 + ty], t);
+                    Y[tz][sy][sx] = t;
+                }
         }
-        if (valid) {
-            const long long ol = (long long)c * dvol + cc;
-            if (a.d_mul_l) dm[0] = __builtin_fmaf(acc[0], a.lll[ol], dm[0]);
-            a.d_lll[ol] = a.mul_l ? acc[0] * m[0] : acc[0];
 #pragma unroll
-            for (int s = 1; s < 8; ++s) {
-                const long long oh = ((long long)c * 7 + (s - 1)) * dvol + cc;
-                if (a.d_mul_h) dm[s] = __builtin_fmaf(acc[s], a.hf[oh], dm[s]);
-                a.d_hf[oh] = a.mul_h ? acc[s] * m[s] : acc[s];
-            }
+        for (int sb = 0; sb < 8; ++sb) {
+            float t = 0.0f;
+#pragma unroll
+            for (int tz = 0; tz < 4; ++tz) t = __builtin_fmaf(Y[tz][(sb >> 1) & 1][sb & 1], a.taps[(sb >> 2) * 4 + tz], t);
+            acc[sb] = t;
+        }
+    } else {
+#pragma unroll 1                      // a rolled z-tap loop keeps the live filter taps to one 16-tap plane
+    for (int tz = 0; tz < 4; ++tz) {
+        const float* pl = s_v + (2 * zl_t + tz) * len + k0;
+        float v[16];
+#pragma unroll
+        for (int ty = 0; ty < 4; ++ty) {
+            const float* row = pl + ty * a.n2;
+#pragma unroll
+            for (int tx = 0; tx < 4; ++tx) v[ty * 4 + tx] = xok[tx] ? row[tx] : 0.0f;
+        }
+#pragma unroll
+        for (int tyx = 0; tyx < 16; ++tyx) {
+            const f32x4 f0v = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8);
+            const f32x4 f1v = *reinterpret_cast<const f32x4*>(s_f + (tz * 16 + tyx) * 8 + 4);
+            acc[0] = __builtin_fmaf(v[tyx], f0v.x, acc[0]); acc[1] = __builtin_fmaf(v[tyx], f0v.y, acc[1]);
+            acc[2] = __builtin_fmaf(v[tyx], f0v.z, acc[2]); acc[3] = __builtin_fmaf(v[tyx], f0v.w, acc[3]);
+            acc[4] = __builtin_fmaf(v[tyx], f1v.x, acc[4]); acc[5] = __builtin_fmaf(v[tyx], f1v.y, acc[5]);
+            acc[6] = __builtin_fmaf(v[tyx], f1v.z, acc[6]); acc[7] = __builtin_fmaf(v[tyx], f1v.w, acc[7]);
         }
     }
-    if (slot > 0) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) s_red[slot - 1][s][lane] = dm[s];
     }
-    __syncthreads();
-    if (slot == 0 && valid) {
+    if (valid) {
+        const long long sp = (long long)iz * plane_cells + fc;
+        if (DROP) {
+            if (a.mul_l) {
+                if (a.d_mul_l) atomicAdd(a.d_mul_l + sp, acc[0] * a.lll[(long long)c * dvol + sp]);
+                acc[0] *= a.mul_l[sp];
+            }
+            if (a.mul_h) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float t = (dm[s] + s_red[0][s][lane]) + (s_red[1][s][lane] + s_red[2][s][lane]);
-            if (s == 0) { if (a.d_mul_l) a.d_mul_l[cc] = t; }
-            else if (a.d_mul_h) a.d_mul_h[(long long)(s - 1) * dvol + cc] = t;
+                for (int s = 1; s < 8; ++s) {
+                    const long long o = (long long)(s - 1) * dvol + sp;
+                    if (a.d_mul_h) atomicAdd(a.d_mul_h + o, acc[s] * a.hf[(long long)c * 7 * dvol + o]);
+                    acc[s] *= a.mul_h[o];
+                }
+            }
         }
+        a.band0[(long long)c * a.cstride0 + sp] = acc[0];
+#pragma unroll
+        for (int s = 1; s < 8; ++s) a.bandh[(long long)c * a.cstrideh + (long long)(s - 1) * dvol + sp] = acc[s];
     }
 }
 
@@ -296,11 +388,6 @@ __global__ __launch_bounds__(256) void last_to_first_kernel(const float* __restr
     }
 }
 
-inline unsigned grid_for(long long total, int block = 256) {
-    long long g = (total + block - 1) / block;
-    return (unsigned)(g < 1 ? 1 : g);
-}
-
 inline int check_level(const void* a, const void* b, const void* c, const void* d, int C, int d0, int d1, int d2,
                        int t0, int t1, int t2) {
     if (!a || !b || !c || !d) return LFGC_E_NULL;
@@ -309,94 +396,124 @@ inline int check_level(const void* a, const void* b, const void* c, const void* 
     return LFGC_OK;
 }
 
-}  // namespace
-
-extern "C" int lfgc_idwt_level_f32(const float* lll, const float* hf, const float* filter_rev, float* out,
-                                   int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream) {
-    const int rc = check_level(lll, hf, filter_rev, out, C, d0, d1, d2, t0, t1, t2);
-    if (rc != LFGC_OK) return rc;
-    IdwtArgs a;
-    a.lll = lll; a.hf = hf; a.filt = filter_rev; a.out = out;
-    a.C = C; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.t0 = t0; a.t1 = t1; a.t2 = t2;
-    a.o0 = (2 * d0 + 2 - t0) / 2; a.o1 = (2 * d1 + 2 - t1) / 2; a.o2 = (2 * d2 + 2 - t2) / 2;
-    const long long total = (long long)C * (d0 + 1) * (d1 + 1) * (d2 + 1);
-    a.mul_l = nullptr; a.mul_h = nullptr; a.thr_l = a.thr_h = 0.0f;
-    hipLaunchKernelGGL(idwt_level_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
+template <typename K, typename A>
+int launch_tiled(K kern, int* lds_limit, const A& a, long long blocks, int lds_bytes, hipStream_t stream) {
+    if (blocks > 0x7fffffffLL || lds_bytes > 160 * 1024) return LFGC_E_UNSUPPORTED;
+    if (lds_bytes > 64 * 1024 && lds_bytes > *lds_limit) {      // raised once per kernel: launches stay graph-capturable
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        *lds_limit = lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
+}
+
+int launch_idwt(IdwtArgs a, bool drop, const float* taps, hipStream_t stream) {
+    if (taps) for (int i = 0; i < 8; ++i) a.taps[i] = taps[i];
+    a.o0 = (2 * a.d0 + 2 - a.t0) / 2; a.o1 = (2 * a.d1 + 2 - a.t1) / 2; a.o2 = (2 * a.d2 + 2 - a.t2) / 2;
+    const int n0 = a.d0 + 1, n1 = a.d1 + 1, n2 = a.d2 + 1;
+    const int span = (kTileCells + n2 - 2) / n2;            // rows a run of 128 cells can straddle beyond its first
+    a.len = ((span + 2) * a.d2 + 2 + 255) / 256 * 256;      // chunk stride: multiple of the workgroup size
+    const long long blocks = (long long)a.C * ((n0 + 1) / 2) * (((long long)n1 * n2 + kTileCells - 1) / kTileCells);
+    const int lds = (512 + 3 * a.len * kRec) * 4;
+    if ((long long)a.d0 * a.d1 * a.d2 > 0x7fffffffLL / 8 || (long long)a.t0 * a.t1 * a.t2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
+    static int lim[4] = {0, 0, 0, 0};
+    if (taps) return drop ? launch_tiled(idwt_level_kernel<true, true>, &lim[3], a, blocks, lds, stream)
+                          : launch_tiled(idwt_level_kernel<false, true>, &lim[2], a, blocks, lds, stream);
+    return drop ? launch_tiled(idwt_level_kernel<true, false>, &lim[1], a, blocks, lds, stream)
+                : launch_tiled(idwt_level_kernel<false, false>, &lim[0], a, blocks, lds, stream);
+}
+
+int launch_analysis(AnalysisArgs a, bool drop, const float* taps, hipStream_t stream) {
+    if (taps) for (int i = 0; i < 8; ++i) a.taps[i] = taps[i];
+    const int span = (kTileCells + a.d2 - 2) / a.d2;
+    a.len = ((2 * span + 3) * a.n2 + 2 * a.d2 + 2 + 255) / 256 * 256;
+    const long long blocks = (long long)a.C * ((a.d0 + 1) / 2) * (((long long)a.d1 * a.d2 + kTileCells - 1) / kTileCells);
+    const int lds = (512 + 6 * a.len) * 4;
+    if ((long long)a.n0 * a.n1 * a.n2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
+    static int lim[4] = {0, 0, 0, 0};
+    if (taps) return drop ? launch_tiled(analysis_kernel<true, true>, &lim[3], a, blocks, lds, stream)
+                          : launch_tiled(analysis_kernel<false, true>, &lim[2], a, blocks, lds, stream);
+    return drop ? launch_tiled(analysis_kernel<true, false>, &lim[1], a, blocks, lds, stream)
+                : launch_tiled(analysis_kernel<false, false>, &lim[0], a, blocks, lds, stream);
+}
+
+}  // namespace
+
+extern "C" int lfgc_idwt_level_f32(const float* lll, const float* hf, const float* filter_rev, const float* taps, float* out,
+                                   int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream) {
+    const int rc = check_level(lll, hf, taps ? (const void*)taps : (const void*)filter_rev, out, C, d0, d1, d2, t0, t1, t2);
+    if (rc != LFGC_OK) return rc;
+    IdwtArgs a = {};
+    a.lll = lll; a.hf = hf; a.filt = filter_rev; a.out = out;
+    a.C = C; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.t0 = t0; a.t1 = t1; a.t2 = t2;
+    return launch_idwt(a, false, taps, (hipStream_t)stream);
 }
 
 extern "C" int lfgc_idwt_level_drop_f32(const float* lll, const float* hf, const float* mul_lll, float thr_lll,
-                                        const float* mul_hf, float thr_hf, const float* filter_rev, float* out,
+                                        const float* mul_hf, float thr_hf, const float* filter_rev, const float* taps, float* out,
                                         int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream) {
-    const int rc = check_level(lll, hf, filter_rev, out, C, d0, d1, d2, t0, t1, t2);
+    const int rc = check_level(lll, hf, taps ? (const void*)taps : (const void*)filter_rev, out, C, d0, d1, d2, t0, t1, t2);
     if (rc != LFGC_OK) return rc;
-    IdwtArgs a;
+    IdwtArgs a = {};
     a.lll = lll; a.hf = hf; a.filt = filter_rev; a.out = out;
     a.C = C; a.d0 = d0; a.d1 = d1; a.d2 = d2; a.t0 = t0; a.t1 = t1; a.t2 = t2;
-    a.o0 = (2 * d0 + 2 - t0) / 2; a.o1 = (2 * d1 + 2 - t1) / 2; a.o2 = (2 * d2 + 2 - t2) / 2;
     a.mul_l = mul_lll; a.mul_h = mul_hf; a.thr_l = thr_lll; a.thr_h = thr_hf;
-    const long long total = (long long)C * (d0 + 1) * (d1 + 1) * (d2 + 1);
-    if (mul_lll || mul_hf)
-        hipLaunchKernelGGL(idwt_level_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(idwt_level_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a);
-    LFGC_HIP_CHECK_LAUNCH();
-    return LFGC_OK;
+    return launch_idwt(a, mul_lll || mul_hf, taps, (hipStream_t)stream);
 }
 
-extern "C" int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_rev, float* d_lll, float* d_hf,
-                                       int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream) {
-    const int rc = check_level(d_out, filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
-    if (rc != LFGC_OK) return rc;
-    AnalysisArgs a;
+static AnalysisArgs adjoint_args(const float* d_out, const float* filter_rev, float* d_lll, float* d_hf,
+                                 int C, int d0, int d1, int d2, int t0, int t1, int t2) {
+    AnalysisArgs a = {};
     a.src = d_out; a.filt = filter_rev; a.band0 = d_lll; a.bandh = d_hf;
     const long long dvol = (long long)d0 * d1 * d2;
     a.cstride0 = dvol; a.cstrideh = 7 * dvol;
     a.C = C; a.n0 = t0; a.n1 = t1; a.n2 = t2;
     a.lo0 = (2 * d0 + 2 - t0) / 2; a.lo1 = (2 * d1 + 2 - t1) / 2; a.lo2 = (2 * d2 + 2 - t2) / 2;
     a.d0 = d0; a.d1 = d1; a.d2 = d2;
-    hipLaunchKernelGGL(analysis_kernel, dim3(grid_for((long long)C * dvol)), dim3(256), 0, (hipStream_t)stream, a);
-    LFGC_HIP_CHECK_LAUNCH();
-    return LFGC_OK;
+    return a;
 }
 
-extern "C" int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* lll, const float* hf,
+extern "C" int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_rev, const float* taps, float* d_lll, float* d_hf,
+                                       int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream) {
+    const int rc = check_level(d_out, taps ? (const void*)taps : (const void*)filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
+    if (rc != LFGC_OK) return rc;
+    return launch_analysis(adjoint_args(d_out, filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2), false, taps, (hipStream_t)stream);
+}
+
+extern "C" int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* taps, const float* lll, const float* hf,
                                             const float* mul_lll, const float* mul_hf, float* d_lll, float* d_hf,
                                             float* d_mul_lll, float* d_mul_hf, int C, int d0, int d1, int d2,
                                             int t0, int t1, int t2, lfgc_stream_t stream) {
-    const int rc = check_level(d_out, filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
+    const int rc = check_level(d_out, taps ? (const void*)taps : (const void*)filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
     if (rc != LFGC_OK) return rc;
     if ((d_mul_lll && (!mul_lll || !lll)) || (d_mul_hf && (!mul_hf || !hf))) return LFGC_E_NULL;
-    AdjointDropArgs a;
-    a.src = d_out; a.filt = filter_rev; a.lll = lll; a.hf = hf; a.mul_l = mul_lll; a.mul_h = mul_hf;
-    a.d_lll = d_lll; a.d_hf = d_hf; a.d_mul_l = d_mul_lll; a.d_mul_h = d_mul_hf;
-    a.C = C; a.n0 = t0; a.n1 = t1; a.n2 = t2;
-    a.lo0 = (2 * d0 + 2 - t0) / 2; a.lo1 = (2 * d1 + 2 - t1) / 2; a.lo2 = (2 * d2 + 2 - t2) / 2;
-    a.d0 = d0; a.d1 = d1; a.d2 = d2;
-    const long long dvol = (long long)d0 * d1 * d2;
-    hipLaunchKernelGGL(adjoint_drop_kernel, dim3(grid_for(dvol, 64)), dim3(256), 0, (hipStream_t)stream, a);
-    LFGC_HIP_CHECK_LAUNCH();
-    return LFGC_OK;
+    AnalysisArgs a = adjoint_args(d_out, filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
+    a.lll = lll; a.hf = hf; a.mul_l = mul_lll; a.mul_h = mul_hf; a.d_mul_l = d_mul_lll; a.d_mul_h = d_mul_hf;
+    const size_t dvol = (size_t)d0 * d1 * d2;
+    hipError_t e = hipSuccess;
+    if (d_mul_lll) e = hipMemsetAsync(d_mul_lll, 0, dvol * sizeof(float), (hipStream_t)stream);
+    if (e == hipSuccess && d_mul_hf) e = hipMemsetAsync(d_mul_hf, 0, 7 * dvol * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return launch_analysis(a, mul_lll || mul_hf, taps, (hipStream_t)stream);
 }
 
-extern "C" int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, float* out,
+extern "C" int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, const float* taps, float* out,
                                   int C, int n0, int n1, int n2, lfgc_stream_t stream) {
-    if (!in || !filter_fwd || !out) return LFGC_E_NULL;
+    if (!in || (!filter_fwd && !taps) || !out) return LFGC_E_NULL;
     if (C < 1 || n0 < 1 || n1 < 1 || n2 < 1) return LFGC_E_SHAPE;
     // _get_padding_size (Torch_Wavelet_Transform.py:59-63): F.pad slots are (last axis lo, hi, ..., first axis
     // lo, hi) while is_odd is indexed first axis first -> the odd bit of axis a pads axis 2-a.
     const int hi0 = 2 + (n2 & 1), hi1 = 2 + (n1 & 1), hi2 = 2 + (n0 & 1);
-    AnalysisArgs a;
+    AnalysisArgs a = {};
     a.src = in; a.filt = filter_fwd;
     a.d0 = (n0 + 2 + hi0 - 4) / 2 + 1; a.d1 = (n1 + 2 + hi1 - 4) / 2 + 1; a.d2 = (n2 + 2 + hi2 - 4) / 2 + 1;
     const long long dvol = (long long)a.d0 * a.d1 * a.d2;
     a.band0 = out; a.bandh = out + dvol;
     a.cstride0 = 8 * dvol; a.cstrideh = 8 * dvol;
     a.C = C; a.n0 = n0; a.n1 = n1; a.n2 = n2; a.lo0 = 2; a.lo1 = 2; a.lo2 = 2;
-    hipLaunchKernelGGL(analysis_kernel, dim3(grid_for((long long)C * dvol)), dim3(256), 0, (hipStream_t)stream, a);
-    LFGC_HIP_CHECK_LAUNCH();
-    return LFGC_OK;
+    return launch_analysis(a, false, taps, (hipStream_t)stream);
 }
 
 extern "C" int lfgc_grid_layout_f32(const float* src, float* dst, int C, int64_t voxels, int channel_stride,

@@ -3,6 +3,7 @@ arithmetic happens in liblfgc.so) and the two autograd Functions of the hot path
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -45,16 +46,69 @@ def grid_channel_stride(C: int) -> int:
 
 # ---- wavelet levels ------------------------------------------------------------------------------------
 
+_TAPS_CACHE = {}      # id(filter tensor) -> (weakref, version, ctypes float[8] or None)
+
+
+def _outer_bank(a: np.ndarray) -> np.ndarray:
+    """(2,4) fp32 taps -> (8,4,4,4) fp32 the way the reference forms it: a[sz][tz] * (a[sy][ty] * a[sx][tx]), s = 4sz+2sy+sx
+    (wavelet_transform/Torch_Wavelet_Transform.py:44-53)."""
+    a = a.astype(np.float32)
+    yx = (a[:, None, :, None] * a[None, :, None, :]).astype(np.float32)               # [sy][sx][ty][tx]
+    out = (a[:, None, None, :, None, None] * yx[None, :, :, None, :, :]).astype(np.float32)   # [sz][sy][sx][tz][ty][tx]
+    return out.reshape(8, 4, 4, 4)
+
+
+def _factor_bank(f3d: np.ndarray) -> Optional[np.ndarray]:
+    """1-D bank (2,4) whose outer product IS the given (8,4,4,4) filter, or None if the filter is not separable."""
+    f3d = f3d.astype(np.float32).reshape(8, 4, 4, 4)
+    c = float(f3d[0, 0, 0, 0])
+    if c == 0.0 or not np.isfinite(f3d).all():
+        return None
+    a0 = np.cbrt(np.float64(c))
+    a = (f3d[[0, 1], 0, 0, :].astype(np.float64) / (a0 * a0)).astype(np.float32)      # bands (0,0,sx), taps along x
+    # exact fp32 taps are within an ulp or two of this estimate: search the neighbours for a bit-exact reconstruction
+    best, best_err = None, np.inf
+    for d_lo in (0, -1, 1, -2, 2):
+        for d_hi in (0, -1, 1, -2, 2):
+            cand = a.copy()
+            for row, d in ((0, d_lo), (1, d_hi)):
+                for _ in range(abs(d)):
+                    cand[row] = np.nextafter(cand[row], np.float32(np.inf) if d > 0 else np.float32(-np.inf))
+            err = float(np.abs(_outer_bank(cand) - f3d).max())
+            if err < best_err:
+                best, best_err = cand, err
+            if err == 0.0:
+                return cand
+    scale = float(np.abs(f3d).max())
+    return best if best_err <= 4e-7 * scale else None
+
+
+def filter_taps(filt: torch.Tensor):
+    """ctypes float[8] = the 1-D bank of a wavelet filter buffer (or None: not separable -> dense stencil).  Costs
+    one 2 KB device-to-host copy the first time a buffer is seen; cached per tensor object and in-place version."""
+    ent = _TAPS_CACHE.get(id(filt))
+    if ent is not None and ent[0]() is filt and ent[1] == filt._version:
+        return ent[2]
+    bank = _factor_bank(filt.detach().float().cpu().numpy())
+    taps = None if bank is None else (ctypes.c_float * 8)(*[float(v) for v in bank.reshape(-1)])
+    if len(_TAPS_CACHE) > 256:
+        for k in [k for k, e in _TAPS_CACHE.items() if e[0]() is None]:
+            del _TAPS_CACHE[k]
+    _TAPS_CACHE[id(filt)] = (weakref.ref(filt), filt._version, taps)
+    return taps
+
+
 def idwt_level(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, target: Sequence[int]) -> torch.Tensor:
     """lll (C,d0,d1,d2), hf (C,7,d0,d1,d2) -> (C,t0,t1,t2)."""
     _require_hip(lll, hf, filter_rev)
+    taps = filter_taps(filter_rev)
     lll, hf, filter_rev = _f32c(lll), _f32c(hf), _f32c(filter_rev)
     C, d0, d1, d2 = lll.shape
     if tuple(hf.shape) != (C, 7, d0, d1, d2):
         raise ValueError('detail bands %s do not match low band %s' % (tuple(hf.shape), tuple(lll.shape)))
     t = [int(v) for v in target]
     out = torch.empty((C, t[0], t[1], t[2]), dtype=torch.float32, device=lll.device)
-    check(_lib.load().lfgc_idwt_level_f32(lll.data_ptr(), hf.data_ptr(), filter_rev.data_ptr(), out.data_ptr(),
+    check(_lib.load().lfgc_idwt_level_f32(lll.data_ptr(), hf.data_ptr(), filter_rev.data_ptr(), taps, out.data_ptr(),
                                           C, d0, d1, d2, t[0], t[1], t[2], _stream(lll)), 'lfgc_idwt_level_f32')
     return out
 
@@ -62,12 +116,13 @@ def idwt_level(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, ta
 def idwt_level_bwd(d_out: torch.Tensor, filter_rev: torch.Tensor, d: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
     """d_out (C,t0,t1,t2) -> (d_lll (C,d0,d1,d2), d_hf (C,7,d0,d1,d2))."""
     _require_hip(d_out, filter_rev)
+    taps = filter_taps(filter_rev)
     d_out, filter_rev = _f32c(d_out), _f32c(filter_rev)
     C, t0, t1, t2 = d_out.shape
     d = [int(v) for v in d]
     d_lll = torch.empty((C, d[0], d[1], d[2]), dtype=torch.float32, device=d_out.device)
     d_hf = torch.empty((C, 7, d[0], d[1], d[2]), dtype=torch.float32, device=d_out.device)
-    check(_lib.load().lfgc_idwt_level_bwd_f32(d_out.data_ptr(), filter_rev.data_ptr(), d_lll.data_ptr(), d_hf.data_ptr(),
+    check(_lib.load().lfgc_idwt_level_bwd_f32(d_out.data_ptr(), filter_rev.data_ptr(), taps, d_lll.data_ptr(), d_hf.data_ptr(),
                                               C, d[0], d[1], d[2], t0, t1, t2, _stream(d_out)), 'lfgc_idwt_level_bwd_f32')
     return d_lll, d_hf
 
@@ -104,11 +159,12 @@ def dwt_out_shape(n: Sequence[int]) -> List[int]:
 def dwt_level(data: torch.Tensor, filter_fwd: torch.Tensor) -> torch.Tensor:
     """data (C,n0,n1,n2) -> (C,8,d0,d1,d2)."""
     _require_hip(data, filter_fwd)
+    taps = filter_taps(filter_fwd)
     data, filter_fwd = _f32c(data), _f32c(filter_fwd)
     C, n0, n1, n2 = data.shape
     d = dwt_out_shape((n0, n1, n2))
     out = torch.empty((C, 8, d[0], d[1], d[2]), dtype=torch.float32, device=data.device)
-    check(_lib.load().lfgc_dwt_level_f32(data.data_ptr(), filter_fwd.data_ptr(), out.data_ptr(), C, n0, n1, n2,
+    check(_lib.load().lfgc_dwt_level_f32(data.data_ptr(), filter_fwd.data_ptr(), taps, out.data_ptr(), C, n0, n1, n2,
                                          _stream(data)), 'lfgc_dwt_level_f32')
     return out
 
@@ -163,6 +219,7 @@ def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> 
     """One IDWT level with the drop factors of its inputs folded in: mul_l (d0,d1,d2) / mul_h (7,d0,d1,d2) or None;
     thr None = plain product, a float = masked straight-through rule (see include/lfgc.h)."""
     _require_hip(lll, hf, filter_rev, mul_l, mul_h)
+    taps = filter_taps(filter_rev)
     lll, hf, filter_rev = _f32c(lll), _f32c(hf), _f32c(filter_rev)
     C, d0, d1, d2 = lll.shape
     if tuple(hf.shape) != (C, 7, d0, d1, d2):
@@ -179,7 +236,7 @@ def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> 
     out = torch.empty((C, t[0], t[1], t[2]), dtype=torch.float32, device=lll.device)
     check(_lib.load().lfgc_idwt_level_drop_f32(
         lll.data_ptr(), hf.data_ptr(), mul_l.data_ptr() if mul_l is not None else None, _thr(thr_l),
-        mul_h.data_ptr() if mul_h is not None else None, _thr(thr_h), filter_rev.data_ptr(), out.data_ptr(),
+        mul_h.data_ptr() if mul_h is not None else None, _thr(thr_h), filter_rev.data_ptr(), taps, out.data_ptr(),
         C, d0, d1, d2, t[0], t[1], t[2], _stream(lll)), 'lfgc_idwt_level_drop_f32')
     return out
 
@@ -187,6 +244,7 @@ def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> 
 def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml: bool, want_dmh: bool, d):
     """Adjoint of idwt_level_drop -> (d_lll, d_hf, d_mul_l or None, d_mul_h or None)."""
     _require_hip(d_out, filter_rev)
+    taps = filter_taps(filter_rev)
     d_out, filter_rev = _f32c(d_out), _f32c(filter_rev)
     C, t0, t1, t2 = d_out.shape
     d = [int(v) for v in d]
@@ -197,7 +255,7 @@ def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml: bool
     d_mh = torch.empty((7, d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dmh else None
     ptr = lambda t: t.data_ptr() if t is not None else None
     check(_lib.load().lfgc_idwt_level_drop_bwd_f32(
-        d_out.data_ptr(), filter_rev.data_ptr(), ptr(lll), ptr(hf), ptr(mul_l), ptr(mul_h), d_lll.data_ptr(),
+        d_out.data_ptr(), filter_rev.data_ptr(), taps, ptr(lll), ptr(hf), ptr(mul_l), ptr(mul_h), d_lll.data_ptr(),
         d_hf.data_ptr(), ptr(d_ml), ptr(d_mh), C, d[0], d[1], d[2], t0, t1, t2, _stream(d_out)),
         'lfgc_idwt_level_drop_bwd_f32')
     return d_lll, d_hf, d_ml, d_mh

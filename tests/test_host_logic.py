@@ -64,7 +64,8 @@ def test_pure_host_entry_points(built_lib):
     assert lib.lfgc_error_string(0) == b'ok'
     assert b'NULL' in lib.lfgc_error_string(-1)
     # NULL / shape errors are reported before anything is launched
-    assert lib.lfgc_idwt_level_f32(None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None) == -1
+    assert lib.lfgc_idwt_level_f32(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None) == -1
+    assert lib.lfgc_penalty_sums_f32(None, 0, None, None) == -1 and lib.lfgc_drop_apply_f32(None, None, 0.0, None, 1, 1, None) == -1
     assert lib.lfgc_forward_f32(ctypes.byref(ok), None, None, 1, 1, 1, None, 0, 0, None, None, None) == -1
     assert lib.lfgc_gt_interp_f32(None, None, None, None, None, 0, 1, 1, 1, None, None) == -1
 

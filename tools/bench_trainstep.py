@@ -24,12 +24,55 @@ def main():
     ap.add_argument('--no-input-grad', action='store_true')
     ap.add_argument('--foreach-adam', action='store_true', help="torch's default (foreach) Adam instead of fused=True")
     ap.add_argument('--graph', action='store_true', help='capture one train step in a HIP graph and replay it')
+    ap.add_argument('--drop-type', default='', choices=['', 'smallify', 'masked_straight_through', 'variational'],
+                    help='pruning layers on the coefficients + their loss (the reference CLI default is smallify)')
+    ap.add_argument('--unfused-drop', action='store_true',
+                    help='comparison: apply the drop factors and penalties with torch ops instead of the fused HIP kernels')
     args = ap.parse_args()
     from latent_feature_grid_compression_amd.data.Interpolation import trilinear_f_interpolation
     from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
     dev = torch.device('cuda:0')
     w = bench.WORKLOADS['headline']
     model = bench.build_model(w, seed=2003, device=dev).train()
+    drop_loss = None
+    if args.drop_type:
+        import torch.nn as nn
+        from latent_feature_grid_compression_amd.model.Smallify_Dropout import SmallifyDropout, SmallifyLoss
+        from latent_feature_grid_compression_amd.model.Straight_Through_Dropout import MaskedWavelet_Straight_Through_Dropout
+        from latent_feature_grid_compression_amd.model.Variational_Dropout_Layer import VariationalDropout, VariationalDropoutLoss
+        cls, a, b = {'smallify': (SmallifyDropout, 0.025, 0.75),
+                     'masked_straight_through': (MaskedWavelet_Straight_Through_Dropout, 0.5, 0.5),
+                     'variational': (VariationalDropout, 0.5, 0.9)}[args.drop_type]
+        layers = [cls(tuple(f.shape[1:]), a, b).to(dev) for f in model.feature_grid]
+
+        class TorchDrop(nn.Module):
+            """The same layer applied the reference's way: a coefficient-sized torch multiply + autograd."""
+            def __init__(self, inner):
+                super().__init__()
+                self.inner = inner
+
+            def forward(self, x):
+                f = self.inner.drop_factor()
+                if f.threshold is None:
+                    return x * f.mul.unsqueeze(0)
+                return (x * (f.mul >= f.threshold) - x * f.mul).detach() + x * f.mul
+
+        model.drop = nn.ModuleList([TorchDrop(l) for l in layers] if args.unfused_drop else layers)
+        if args.drop_type == 'variational':
+            crit = VariationalDropoutLoss(size_volume=255.0 ** 3, batch_size=32768.0, weight_dkl=1e-6, weight_weights=1e-8)
+            if args.unfused_drop:
+                def drop_loss(pred, gt):
+                    dkl = sum(l.inner_dkl() for l in layers)
+                    raise SystemExit('unfused variational loss not wired; use smallify for the comparison')
+            else:
+                drop_loss = lambda pred, gt: crit(model, pred, gt, torch.full_like(pred, -2.0), 0.0)[0]
+        elif args.unfused_drop:
+            key = 'betas' if args.drop_type == 'smallify' else 'mask_values'
+            drop_loss = lambda pred, gt: loss_fn(pred, gt) + 1e-6 * sum(torch.abs(getattr(l, key)).sum() for l in layers) + \
+                1e-8 * sum(torch.sum(torch.abs(f) ** 2) for f in model.feature_grid)
+        else:
+            sl = SmallifyLoss(1e-6, 1e-8)
+            drop_loss = lambda pred, gt: loss_fn(pred, gt) + sl(model)
     rng = np.random.Generator(np.random.PCG64(1003))
     vol = torch.from_numpy(rng.uniform(-1, 1, (255, 255, 255)).astype(np.float32)).to(dev)
     ds = IndexDataset((255, 255, 255), 16, build_index_table=False)
@@ -55,7 +98,7 @@ def main():
         opt.zero_grad()
         pred = model(norm).squeeze(-1)
         gt = trilinear_f_interpolation(raw, vol, mn, mx, rs)
-        loss = loss_fn(pred, gt)
+        loss = loss_fn(pred, gt) if drop_loss is None else drop_loss(pred, gt)
         if backward:
             loss.backward()
             opt.step()
@@ -85,7 +128,8 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         out['train_step_graph'] = {'ms_per_step': dt * 1e3, 'Msamples_per_s': n / dt / 1e6}
         out['final_loss'] = float(static_loss)
-        out['config'] = 'cfg3 train step replayed from one HIP graph (same work as train_step)'
+        out['config'] = 'cfg3 train step replayed from one HIP graph (same work as train_step); drop %s%s' % (
+            args.drop_type or 'none', ' (torch ops)' if args.unfused_drop else '')
         print(json.dumps(out))
         return
     for name, bw in (('fwd_only', False), ('train_step', True)):
@@ -99,8 +143,9 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         out[name] = {'ms_per_step': dt * 1e3, 'Msamples_per_s': n / dt / 1e6}
     out['final_loss'] = float(loss)
-    out['config'] = 'cfg3: 64^3x32ch grid, MLP 4x128, 32768 lattice samples/step, fp32, Adam; input grad %s' % (
-        'off' if args.no_input_grad else 'on (reference sets requires_grad on positions)')
+    out['config'] = 'cfg3: 64^3x32ch grid, MLP 4x128, 32768 lattice samples/step, fp32, Adam; input grad %s; drop %s%s' % (
+        'off' if args.no_input_grad else 'on (reference sets requires_grad on positions)', args.drop_type or 'none',
+        ' (torch ops)' if args.unfused_drop else '')
     print(json.dumps(out))
 
 
