@@ -106,8 +106,9 @@ int lfgc_idwt_level_drop_f32(const float* lll, const float* hf, const float* mul
                              const float* mul_hf, float threshold_hf, const float* filter_rev, const float* taps, float* out,
                              int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
 
-/* Adjoint of lfgc_idwt_level_drop_f32: d_lll / d_hf are the gradients of the UN-multiplied inputs;
- * d_mul_lll (d0,d1,d2) / d_mul_hf (7,d0,d1,d2) receive the factor gradients (NULL = not wanted; needs lll / hf). */
+/* Adjoint of lfgc_idwt_level_drop_f32: d_lll / d_hf are OVERWRITTEN with the gradients of the UN-multiplied inputs;
+ * the factor gradients are ADDED (float atomics over the channels) into d_mul_lll (d0,d1,d2) / d_mul_hf (7,d0,d1,d2),
+ * which the caller zero-fills beforehand (NULL = not wanted; wanting them needs lll / hf). */
 int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* taps, const float* lll, const float* hf,
                                  const float* mul_lll, const float* mul_hf, float* d_lll, float* d_hf,
                                  float* d_mul_lll, float* d_mul_hf, int C, int d0, int d1, int d2,
@@ -124,6 +125,10 @@ int lfgc_drop_apply_bwd_f32(const float* d_out, const float* x, const float* mul
  * reference's operation order (bit-identical state; the reference moves betas to the CPU every step). */
 int lfgc_sign_variance_update_f32(const float* betas, float* ema, float* emavar, float momentum, int64_t n,
                                   lfgc_stream_t stream);
+/* The same step for all drop layers of a model in one launch: host arrays of n_layers (<= LFGC_PENALTY_MAX_TERMS)
+ * device pointers and lengths. */
+int lfgc_sign_variance_update_multi_f32(const float* const* betas, float* const* ema, float* const* emavar,
+                                        const int64_t* n, int n_layers, float momentum, lfgc_stream_t stream);
 
 /* Penalty terms of the pruning losses as ONE multi-tensor reduction (SmallifyLoss, model/Smallify_Dropout.py:21-40;
  * VariationalDropoutLoss._collect_penalties + calculate_Dkl, model/Variational_Dropout_Layer.py:48-53, :115-122). */
@@ -139,7 +144,10 @@ typedef struct lfgc_penalty_term {
     int64_t n;
     int32_t kind;
 } lfgc_penalty_term;
-/* terms: host array; sums: device double[n_terms], overwritten (fp64 accumulation). */
+/* terms: host array; sums: device double[LFGC_PENALTY_SUMS_DOUBLES(n_terms)]: the first n_terms entries receive the
+ * results (fp64 accumulation, fixed summation order: bitwise repeatable), the rest is scratch (per-workgroup partials). */
+#define LFGC_PENALTY_BLOCKS 1024
+#define LFGC_PENALTY_SUMS_DOUBLES(n_terms) ((n_terms) * (1 + LFGC_PENALTY_BLOCKS))
 int lfgc_penalty_sums_f32(const lfgc_penalty_term* terms, int n_terms, double* sums, lfgc_stream_t stream);
 /* Gradients: grad_a[t] (and grad_b[t] for DKL terms) are OVERWRITTEN with d_sums[t] * d(term t)/d(a | b);
  * d_sums device float[n_terms]; grad_a / grad_b host arrays of device pointers. */

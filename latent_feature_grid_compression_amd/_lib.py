@@ -32,6 +32,7 @@ class PenaltyTerm(Structure):
 
 PENALTY_L1, PENALTY_L2, PENALTY_DKL = 0, 1, 2
 PENALTY_MAX_TERMS = 16
+PENALTY_BLOCKS = 1024             # LFGC_PENALTY_SUMS_DOUBLES(n) = n * (1 + PENALTY_BLOCKS)
 _PP = POINTER(c_void_p)
 _TAPS = POINTER(c_float)          # host float[8] (1-D filter bank) or None
 
@@ -49,6 +50,7 @@ SIGNATURES = {
     'lfgc_drop_apply_f32': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_void_p]),
     'lfgc_drop_apply_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'lfgc_sign_variance_update_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
+    'lfgc_sign_variance_update_multi_f32': (c_int, [_PP, _PP, _PP, POINTER(c_int64), c_int, c_float, c_void_p]),
     'lfgc_penalty_sums_f32': (c_int, [POINTER(PenaltyTerm), c_int, c_void_p, c_void_p]),
     'lfgc_penalty_grads_f32': (c_int, [POINTER(PenaltyTerm), c_int, c_void_p, _PP, _PP, c_void_p]),
     'lfgc_mlp_supported': (c_int, [POINTER(MlpDesc)]),

@@ -56,13 +56,43 @@ __global__ __launch_bounds__(256) void sign_variance_kernel(const float* __restr
     emavar[i] = __fmul_rn(__fsub_rn(1.0f, mom), __fadd_rn(emavar[i], __fmul_rn(mom, __fmul_rn(phi, phi))));
 }
 
+struct TrackerArgs {
+    const float* betas[LFGC_PENALTY_MAX_TERMS];
+    float* ema[LFGC_PENALTY_MAX_TERMS];
+    float* emavar[LFGC_PENALTY_MAX_TERMS];
+    long long n[LFGC_PENALTY_MAX_TERMS];
+    int block_start[LFGC_PENALTY_MAX_TERMS + 1];
+    int n_layers;
+    float mom;
+};
+
+__global__ __launch_bounds__(256) void sign_variance_multi_kernel(const TrackerArgs a) {
+    int t = 0;
+    while (t + 1 < a.n_layers && (int)blockIdx.x >= a.block_start[t + 1]) ++t;
+    const long long i = (long long)(blockIdx.x - a.block_start[t]) * 256 + threadIdx.x;
+    if (i >= a.n[t]) return;
+    const float b = a.betas[t][i];
+    const float sgn = b != b ? b : (float)((b > 0.0f) - (b < 0.0f));
+    const float e = a.ema[t][i];
+    const float phi = __fsub_rn(sgn, e);
+    a.ema[t][i] = __fadd_rn(e, __fmul_rn(a.mom, phi));
+    a.emavar[t][i] = __fmul_rn(__fsub_rn(1.0f, a.mom), __fadd_rn(a.emavar[t][i], __fmul_rn(a.mom, __fmul_rn(phi, phi))));
+}
+
 constexpr int kMaxTerms = LFGC_PENALTY_MAX_TERMS;
 struct PenaltyArgs {
     lfgc_penalty_term term[kMaxTerms];
     float* grad_a[kMaxTerms];
     float* grad_b[kMaxTerms];
+    int block_start[kMaxTerms + 1];   // 1-D grid: blocks [block_start[t], block_start[t+1]) work on term t
     int n_terms;
 };
+
+__device__ __forceinline__ int term_of_block(const PenaltyArgs& a, int block) {
+    int t = 0;
+    while (t + 1 < a.n_terms && block >= a.block_start[t + 1]) ++t;
+    return t;
+}
 
 // Molchanov et al. constants as the reference multiplies them into fp32 tensors (Variational_Dropout_Layer.py:74-77)
 __device__ __forceinline__ double kl_k1() { return (double)0.63576f; }
@@ -79,25 +109,55 @@ __device__ __forceinline__ double penalty_value(int kind, float a, float b) {
 }
 
 __global__ __launch_bounds__(256) void penalty_sums_kernel(const PenaltyArgs a, double* __restrict__ sums) {
-    const int t = blockIdx.y;
+    const int t = term_of_block(a, blockIdx.x);
     const lfgc_penalty_term term = a.term[t];
-    double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < term.n; i += (long long)gridDim.x * 256)
-        acc += penalty_value(term.kind, term.a[i], term.kind == LFGC_PENALTY_DKL ? term.b[i] : 0.0f);
+    const int nb = a.block_start[t + 1] - a.block_start[t];
+    const long long first = (long long)(blockIdx.x - a.block_start[t]) * 1024 + threadIdx.x, stride = (long long)nb * 1024;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    const bool dkl = term.kind == LFGC_PENALTY_DKL;
+    for (long long i = first; i < term.n; i += stride) {  // 4 independent loads / accumulators per pass
+        const long long i1 = i + 256, i2 = i + 512, i3 = i + 768;
+        const float a0 = term.a[i], a1 = i1 < term.n ? term.a[i1] : 0.0f, a2 = i2 < term.n ? term.a[i2] : 0.0f,
+                    a3 = i3 < term.n ? term.a[i3] : 0.0f;
+        if (!dkl) {
+            acc0 += penalty_value(term.kind, a0, 0.0f); acc1 += penalty_value(term.kind, a1, 0.0f);
+            acc2 += penalty_value(term.kind, a2, 0.0f); acc3 += penalty_value(term.kind, a3, 0.0f);
+        } else {
+            acc0 += penalty_value(LFGC_PENALTY_DKL, a0, term.b[i]);
+            if (i1 < term.n) acc1 += penalty_value(LFGC_PENALTY_DKL, a1, term.b[i1]);
+            if (i2 < term.n) acc2 += penalty_value(LFGC_PENALTY_DKL, a2, term.b[i2]);
+            if (i3 < term.n) acc3 += penalty_value(LFGC_PENALTY_DKL, a3, term.b[i3]);
+        }
+    }
+    double acc = (acc0 + acc1) + (acc2 + acc3);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     __shared__ double s[4];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sums[t], (s[0] + s[1]) + (s[2] + s[3]));
+    // per-block partial; a second tiny kernel folds them in a fixed order (same-address fp64 atomics from thousands of
+    // blocks serialise at ~20 ns each, and a last-block fold needs device-scope fences = L2 write-backs on this chip)
+    if (threadIdx.x == 0) sums[a.n_terms + blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void penalty_fold_kernel(const PenaltyArgs a, double* __restrict__ sums) {
+    const int t = blockIdx.x;
+    double acc = 0.0;
+    for (int b = a.block_start[t] + threadIdx.x; b < a.block_start[t + 1]; b += 256) acc += sums[a.n_terms + b];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[t] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 __global__ __launch_bounds__(256) void penalty_grads_kernel(const PenaltyArgs a, const float* __restrict__ d_sums) {
-    const int t = blockIdx.y;
+    const int t = term_of_block(a, blockIdx.x);
     const lfgc_penalty_term term = a.term[t];
     const float g = d_sums[t];
     float* ga = a.grad_a[t];
     float* gb = a.grad_b[t];
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < term.n; i += (long long)gridDim.x * 256) {
+    const int nb = a.block_start[t + 1] - a.block_start[t];
+    for (long long i = (long long)(blockIdx.x - a.block_start[t]) * 256 + threadIdx.x; i < term.n; i += (long long)nb * 256) {
         const float v = term.a[i];
         if (term.kind == LFGC_PENALTY_L1) {
             ga[i] = g * (float)((v > 0.0f) - (v < 0.0f));
@@ -152,6 +212,26 @@ extern "C" int lfgc_sign_variance_update_f32(const float* betas, float* ema, flo
     return LFGC_OK;
 }
 
+extern "C" int lfgc_sign_variance_update_multi_f32(const float* const* betas, float* const* ema, float* const* emavar,
+                                                   const int64_t* n, int n_layers, float momentum, lfgc_stream_t stream) {
+    if (!betas || !ema || !emavar || !n) return LFGC_E_NULL;
+    if (n_layers < 1 || n_layers > LFGC_PENALTY_MAX_TERMS) return LFGC_E_SHAPE;
+    TrackerArgs a;
+    int total = 0;
+    for (int t = 0; t < n_layers; ++t) {
+        if (!betas[t] || !ema[t] || !emavar[t]) return LFGC_E_NULL;
+        if (n[t] < 1) return LFGC_E_SHAPE;
+        a.betas[t] = betas[t]; a.ema[t] = ema[t]; a.emavar[t] = emavar[t]; a.n[t] = n[t];
+        a.block_start[t] = total;
+        total += (int)((n[t] + 255) / 256);
+    }
+    a.block_start[n_layers] = total;
+    a.n_layers = n_layers; a.mom = momentum;
+    hipLaunchKernelGGL(sign_variance_multi_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
 static int penalty_check(const lfgc_penalty_term* terms, int n_terms, long long* max_n) {
     if (!terms) return LFGC_E_NULL;
     if (n_terms < 1 || n_terms > LFGC_PENALTY_MAX_TERMS) return LFGC_E_SHAPE;
@@ -172,9 +252,12 @@ extern "C" int lfgc_penalty_sums_f32(const lfgc_penalty_term* terms, int n_terms
     PenaltyArgs a;
     for (int t = 0; t < n_terms; ++t) { a.term[t] = terms[t]; a.grad_a[t] = nullptr; a.grad_b[t] = nullptr; }
     a.n_terms = n_terms;
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * n_terms, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(penalty_sums_kernel, dim3(blocks_for(max_n, 256), n_terms), dim3(256), 0, (hipStream_t)stream, a, sums);
+    int total = 0;
+    for (int t = 0; t < n_terms; ++t) { a.block_start[t] = total; total += (int)blocks_for((terms[t].n + 3) / 4, LFGC_PENALTY_BLOCKS); }
+    a.block_start[n_terms] = total;
+    hipLaunchKernelGGL(penalty_sums_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a, sums);
+    LFGC_HIP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(penalty_fold_kernel, dim3(n_terms), dim3(256), 0, (hipStream_t)stream, a, sums);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }
@@ -193,7 +276,10 @@ extern "C" int lfgc_penalty_grads_f32(const lfgc_penalty_term* terms, int n_term
         if (!a.grad_a[t] || (terms[t].kind == LFGC_PENALTY_DKL && !a.grad_b[t])) return LFGC_E_NULL;
     }
     a.n_terms = n_terms;
-    hipLaunchKernelGGL(penalty_grads_kernel, dim3(blocks_for(max_n, 1024), n_terms), dim3(256), 0, (hipStream_t)stream, a, d_sums);
+    int total = 0;
+    for (int t = 0; t < n_terms; ++t) { a.block_start[t] = total; total += (int)blocks_for(terms[t].n, 2048); }
+    a.block_start[n_terms] = total;
+    hipLaunchKernelGGL(penalty_grads_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a, d_sums);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }

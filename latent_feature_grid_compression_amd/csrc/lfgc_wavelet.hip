@@ -491,11 +491,6 @@ extern "C" int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* fil
     if ((d_mul_lll && (!mul_lll || !lll)) || (d_mul_hf && (!mul_hf || !hf))) return LFGC_E_NULL;
     AnalysisArgs a = adjoint_args(d_out, filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
     a.lll = lll; a.hf = hf; a.mul_l = mul_lll; a.mul_h = mul_hf; a.d_mul_l = d_mul_lll; a.d_mul_h = d_mul_hf;
-    const size_t dvol = (size_t)d0 * d1 * d2;
-    hipError_t e = hipSuccess;
-    if (d_mul_lll) e = hipMemsetAsync(d_mul_lll, 0, dvol * sizeof(float), (hipStream_t)stream);
-    if (e == hipSuccess && d_mul_hf) e = hipMemsetAsync(d_mul_hf, 0, 7 * dvol * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
     return launch_analysis(a, mul_lll || mul_hf, taps, (hipStream_t)stream);
 }
 

@@ -48,6 +48,21 @@ class DropoutLayer(torch.nn.Module):
         with per-forward side effects (sign tracker step, random draw) perform them here."""
         return None
 
+    @staticmethod
+    def prepare(layers) -> None:
+        """Called by the model once per decode with all its drop layers, before their drop_factor(): lets a layer type
+        batch its per-forward side effects over the layers (one launch instead of one per layer)."""
+        groups = {}
+        for layer in layers:
+            if isinstance(layer, DropoutLayer):
+                groups.setdefault(type(layer), []).append(layer)
+        for cls, group in groups.items():
+            cls._prepare_group(group)
+
+    @classmethod
+    def _prepare_group(cls, group) -> None:
+        return None
+
     def forward(self, x):
         f = self.drop_factor()
         if f is None:

@@ -97,6 +97,7 @@ class Feature_Grid_Model(nn.Module):
         name their per-coefficient factor -- the multiply happens inside the IDWT kernels --, any other module
         (nn.Identity, a reference DropoutLayer object handed in by the caller) is called as it is."""
         coeffs, factors, thresholds = [], [], []
+        DropoutLayer.prepare(self.drop)
         for g, d in zip(self.feature_grid, self.drop):
             f = d.drop_factor() if isinstance(d, DropoutLayer) else None
             if f is None and not isinstance(d, (nn.Identity, DropoutLayer)):

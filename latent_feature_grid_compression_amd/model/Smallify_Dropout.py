@@ -68,13 +68,34 @@ class SmallifyDropout(DropoutLayer):
         self.betas = nn.Parameter(torch.empty(size).normal_(0, 1), requires_grad=True)
         self.tracker = SmallifySignVarianceTracker(self.c, sign_variance_momentum, self.threshold, self.betas)
         self.d_mask = None
+        self._tracker_stepped = False
+
+    @classmethod
+    def _prepare_group(cls, group) -> None:
+        """One launch advances the sign trackers of all active layers that share a momentum."""
+        by_mom = {}
+        for l in group:
+            if l.training and l.d_mask is None and l.betas.is_cuda:
+                by_mom.setdefault(float(l.tracker.sign_variance_momentum), []).append(l)
+        for mom, ls in by_mom.items():
+            if len(ls) < 2 or len(ls) > _lib.PENALTY_MAX_TERMS:
+                continue
+            for l in ls:
+                l.tracker._follow(l.betas)
+            ops.sign_variance_update_multi([l.betas for l in ls], [l.tracker.EMA for l in ls],
+                                           [l.tracker.EMAVar for l in ls], mom)
+            for l in ls:
+                l._tracker_stepped = True
 
     def drop_factor(self):
         if not self.training:
             return None                                   # reference :55: eval is the identity
         if self.d_mask is not None:
             return DropFactor(self.d_mask.to(self.betas.device, torch.float32))
-        self.tracker.sign_variance_pruning_onlyVar(self.betas)
+        if self._tracker_stepped:
+            self._tracker_stepped = False                 # done for this forward by _prepare_group
+        else:
+            self.tracker.sign_variance_pruning_onlyVar(self.betas)
         return DropFactor(self.betas)
 
     def l1_loss(self):
@@ -108,10 +129,13 @@ class SmallifySignVarianceTracker:
         with torch.no_grad():
             return torch.sign(betas.detach()).clone(), torch.zeros(self.c, device=betas.device)
 
-    def _step(self, betas):
+    def _follow(self, betas):
         if self.EMA.device != betas.device:
             self.EMA = self.EMA.to(betas.device).contiguous()
             self.EMAVar = self.EMAVar.to(betas.device).contiguous()
+
+    def _step(self, betas):
+        self._follow(betas)
         ops.sign_variance_update(betas, self.EMA, self.EMAVar, self.sign_variance_momentum)
 
     def sign_variance_pruning_onlyVar(self, betas):

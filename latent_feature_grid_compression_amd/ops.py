@@ -241,8 +241,9 @@ def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> 
     return out
 
 
-def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml: bool, want_dmh: bool, d):
-    """Adjoint of idwt_level_drop -> (d_lll, d_hf, d_mul_l or None, d_mul_h or None)."""
+def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml, want_dmh, d):
+    """Adjoint of idwt_level_drop -> (d_lll, d_hf, d_mul_l or None, d_mul_h or None).  want_dml / want_dmh: False, True
+    (a zero tensor is allocated) or a ZERO-FILLED tensor of the factor's shape to accumulate into."""
     _require_hip(d_out, filter_rev)
     taps = filter_taps(filter_rev)
     d_out, filter_rev = _f32c(d_out), _f32c(filter_rev)
@@ -251,8 +252,10 @@ def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml: bool
     dev = d_out.device
     d_lll = torch.empty((C, d[0], d[1], d[2]), dtype=torch.float32, device=dev)
     d_hf = torch.empty((C, 7, d[0], d[1], d[2]), dtype=torch.float32, device=dev)
-    d_ml = torch.empty((d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dml else None
-    d_mh = torch.empty((7, d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dmh else None
+    d_ml = want_dml if torch.is_tensor(want_dml) else (
+        torch.zeros((d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dml else None)
+    d_mh = want_dmh if torch.is_tensor(want_dmh) else (
+        torch.zeros((7, d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dmh else None)
     ptr = lambda t: t.data_ptr() if t is not None else None
     check(_lib.load().lfgc_idwt_level_drop_bwd_f32(
         d_out.data_ptr(), filter_rev.data_ptr(), taps, ptr(lll), ptr(hf), ptr(mul_l), ptr(mul_h), d_lll.data_ptr(),
@@ -339,12 +342,20 @@ class DecodeVolumeDropFn(torch.autograd.Function):
         C = ctx.dims[0][0]
         g = to_channel_first(d_out, C) if ctx.channel_last else d_out
         d_coef, d_fac = [None] * n, [None] * n
+        # the factor gradients are accumulated with atomics: one zero fill for all of them
+        sizes = [int(np.prod(ctx.dims[i][1:])) if ctx.want[i] else 0 for i in range(n)]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=g.device) if sum(sizes) else None
+        zeroed, at = [False] * n, 0
+        for i in range(n):
+            if sizes[i]:
+                zeroed[i] = flat[at:at + sizes[i]].view(ctx.dims[i][1:])
+                at += sizes[i]
         for lvl in range(n - 1, 0, -1):
             first = lvl == 1
             ml = factors[0] if first else None
             g, d_hf, d_ml, d_mh = idwt_level_drop_bwd(
                 g, ctx.filter_rev, coeffs[0] if first else None, coeffs[lvl], ml, factors[lvl],
-                first and ctx.want[0], ctx.want[lvl], ctx.dims[lvl][2:])
+                zeroed[0] if first else False, zeroed[lvl], ctx.dims[lvl][2:])
             d_coef[lvl], d_fac[lvl] = d_hf, d_mh
             if first:
                 d_fac[0] = d_ml
@@ -360,6 +371,21 @@ def sign_variance_update(betas: torch.Tensor, ema: torch.Tensor, emavar: torch.T
     b = _f32c(betas.detach())
     check(_lib.load().lfgc_sign_variance_update_f32(b.data_ptr(), ema.data_ptr(), emavar.data_ptr(), float(momentum),
                                                     b.numel(), _stream(b)), 'lfgc_sign_variance_update_f32')
+
+
+def sign_variance_update_multi(betas, emas, emavars, momentum: float) -> None:
+    """sign_variance_update for all drop layers of a model in one launch."""
+    bs = [_f32c(b.detach()) for b in betas]
+    _require_hip(*bs, *emas, *emavars)
+    for e, v in zip(emas, emavars):
+        if not (e.is_contiguous() and v.is_contiguous() and e.dtype == v.dtype == torch.float32):
+            raise ValueError('tracker state must be contiguous fp32')
+    pb, _k1 = _lib.ptr_array([b.data_ptr() for b in bs])
+    pe, _k2 = _lib.ptr_array([e.data_ptr() for e in emas])
+    pv, _k3 = _lib.ptr_array([v.data_ptr() for v in emavars])
+    ns = (ctypes.c_int64 * len(bs))(*[b.numel() for b in bs])
+    check(_lib.load().lfgc_sign_variance_update_multi_f32(pb, pe, pv, ns, len(bs), float(momentum), _stream(bs[0])),
+          'lfgc_sign_variance_update_multi_f32')
 
 
 def _penalty_terms(kinds, tensors):
@@ -387,11 +413,11 @@ class PenaltyFn(torch.autograd.Function):
         kinds = [int(k) for k in kinds]
         terms, keep = _penalty_terms(kinds, tensors)
         dev = keep[0][0].device
-        sums = torch.empty(len(kinds), dtype=torch.float64, device=dev)
+        sums = torch.empty(len(kinds) * (1 + _lib.PENALTY_BLOCKS), dtype=torch.float64, device=dev)   # results + scratch
         check(_lib.load().lfgc_penalty_sums_f32(terms, len(kinds), sums.data_ptr(), _stream(sums)), 'lfgc_penalty_sums_f32')
         ctx.kinds = kinds
         ctx.save_for_backward(*[t.detach() for t in tensors])
-        return sums.float()
+        return sums[:len(kinds)].float()
 
     @staticmethod
     def backward(ctx, d_sums):
