@@ -155,6 +155,47 @@ int lfgc_penalty_grads_f32(const lfgc_penalty_term* terms, int n_terms, const fl
                            float* const* grad_a, float* const* grad_b, lfgc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Binary checkpoint codec, device side.  The reference's store_model_parameters /
+ * restore_model (model/model_utils.py:120-332) do the per-coefficient work in Python lists and strings; these entry
+ * points are that work on device buffers.  File layout, header and the hidden-layer / final-layer fields are host code
+ * (latent_feature_grid_compression_amd/model/model_utils.py); byte order of every packed stream: MSB first.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Bit mask "1 = coefficient != 0" of x[0..n) (model_utils.py:204-208 + binary_writing :89-107): mask has (n+7)/8 bytes,
+ * bit i at byte i/8, MSB first, tail bits zero. */
+int lfgc_codec_mask_f32(const float* x, int64_t n, uint8_t* mask, lfgc_stream_t stream);
+
+/* Workspace of the two order-preserving passes below. */
+int64_t lfgc_codec_select_workspace_bytes(int64_t n);
+
+/* out[0..*count) = the non-zero values of x in order (model_utils.py:210-212: nonzero + index); count: device int64. */
+int lfgc_codec_compact_f32(const float* x, int64_t n, float* out, int64_t* count, void* workspace,
+                           int64_t workspace_bytes, lfgc_stream_t stream);
+
+/* out[i] = mask bit (bit_offset + i) ? values[rank of that bit among the set bits of [bit_offset, bit_offset + i)] : 0
+ * (restore_model's zero re-insertion, model_utils.py:297-306, there one np.insert per pruned element). */
+int lfgc_codec_expand_f32(const uint8_t* mask, int64_t bit_offset, int64_t n, const float* values, float* out,
+                          void* workspace, int64_t workspace_bytes, lfgc_stream_t stream);
+
+/* k-entry codebook (k <= 256) of the values x[0..n) by `iterations` Lloyd steps from the SORTED initial centres passed in
+ * `centres` (overwritten, stays sorted); labels (uint8, optional) = index of the nearest final centre.  Replaces
+ * kmeans_quantization (model_utils.py:65-70: scikit-learn KMeans(n_clusters, n_init=4), unseeded -> the reference's own
+ * codebooks are not reproducible; any codebook is a valid file).  Deterministic: per-workgroup partial sums folded in a
+ * fixed order. */
+/* HOST function (no device work): k sorted initial centres from a SORTED host sample of the values (n <= 2^24) by
+ * agglomerative merging of adjacent clusters (Ward's criterion) until k remain; n <= k: the values themselves, padded. */
+int lfgc_codec_ward_init_host(const float* sorted_values, int64_t n, int k, float* centres);
+#define LFGC_CODEC_KMEANS_PARTS 1024
+int64_t lfgc_codec_kmeans_workspace_bytes(int k);
+int lfgc_codec_kmeans1d_f32(const float* x, int64_t n, int k, float* centres, uint8_t* labels, int iterations,
+                            void* workspace, int64_t workspace_bytes, lfgc_stream_t stream);
+
+/* out[i] = centres[label_i], label_i = bits [bits*i, bits*(i+1)) of `packed`, MSB first, 1 <= bits <= 16
+ * (read_in_data_quantized, model_utils.py:255-275). */
+int lfgc_codec_dequant_f32(const uint8_t* packed, int64_t packed_bytes, int bits, int64_t n, const float* centres,
+                           float* out, lfgc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused sample + Fourier-embed + MLP decoder
  * ---------------------------------------------------------------------------------------------- */
 

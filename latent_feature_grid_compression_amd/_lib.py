@@ -53,6 +53,14 @@ SIGNATURES = {
     'lfgc_sign_variance_update_multi_f32': (c_int, [_PP, _PP, _PP, POINTER(c_int64), c_int, c_float, c_void_p]),
     'lfgc_penalty_sums_f32': (c_int, [POINTER(PenaltyTerm), c_int, c_void_p, c_void_p]),
     'lfgc_penalty_grads_f32': (c_int, [POINTER(PenaltyTerm), c_int, c_void_p, _PP, _PP, c_void_p]),
+    'lfgc_codec_mask_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    'lfgc_codec_select_workspace_bytes': (c_int64, [c_int64]),
+    'lfgc_codec_compact_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'lfgc_codec_expand_f32': (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'lfgc_codec_ward_init_host': (c_int, [POINTER(c_float), c_int64, c_int, POINTER(c_float)]),
+    'lfgc_codec_kmeans_workspace_bytes': (c_int64, [c_int]),
+    'lfgc_codec_kmeans1d_f32': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    'lfgc_codec_dequant_f32': (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     'lfgc_mlp_supported': (c_int, [POINTER(MlpDesc)]),
     'lfgc_grid_channel_stride': (c_int, [c_int]),
     'lfgc_packed_bytes': (c_int64, [POINTER(MlpDesc)]),

@@ -550,6 +550,90 @@ class SampleDecodeFn(torch.autograd.Function):
         return (None, d_pos, d_grid, None, None, None) + tuple(d_w) + tuple(d_b)
 
 
+# ---- binary checkpoint codec, device side -------------------------------------------
+
+def _flat_f32(x: torch.Tensor) -> torch.Tensor:
+    _require_hip(x)
+    return _f32c(x.detach()).reshape(-1)
+
+
+def _select_workspace(n: int, device) -> torch.Tensor:
+    nbytes = int(_lib.load().lfgc_codec_select_workspace_bytes(int(n)))
+    return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
+
+
+def codec_mask(x: torch.Tensor) -> torch.Tensor:
+    """uint8 (ceil(n/8),): bit i (MSB first) = x.flat[i] != 0."""
+    x = _flat_f32(x)
+    mask = torch.empty((x.numel() + 7) // 8, dtype=torch.uint8, device=x.device)
+    check(_lib.load().lfgc_codec_mask_f32(x.data_ptr(), x.numel(), mask.data_ptr(), _stream(x)), 'lfgc_codec_mask_f32')
+    return mask
+
+
+def codec_compact(x: torch.Tensor) -> torch.Tensor:
+    """The non-zero values of x in order (1-D).  Synchronises once to learn their number."""
+    x = _flat_f32(x)
+    out = torch.empty_like(x)
+    count = torch.zeros(1, dtype=torch.int64, device=x.device)
+    ws = _select_workspace(x.numel(), x.device)
+    check(_lib.load().lfgc_codec_compact_f32(x.data_ptr(), x.numel(), out.data_ptr(), count.data_ptr(), ws.data_ptr(),
+                                             ws.numel() * 8, _stream(x)), 'lfgc_codec_compact_f32')
+    return out[:int(count.item())]
+
+
+def codec_expand(mask: torch.Tensor, bit_offset: int, n: int, values: torch.Tensor) -> torch.Tensor:
+    """(n,) fp32: values scattered to the set bits [bit_offset, bit_offset + n) of the MSB-first mask, zeros elsewhere."""
+    _require_hip(mask, values)
+    if mask.dtype != torch.uint8 or (int(bit_offset) + int(n) + 7) // 8 > mask.numel():
+        raise ValueError('mask too short for %d bits at offset %d' % (n, bit_offset))
+    values = _f32c(values).reshape(-1)
+    if values.numel() == 0:
+        values = torch.zeros(1, dtype=torch.float32, device=mask.device)
+    out = torch.empty(int(n), dtype=torch.float32, device=mask.device)
+    ws = _select_workspace(n, mask.device)
+    check(_lib.load().lfgc_codec_expand_f32(mask.contiguous().data_ptr(), int(bit_offset), int(n), values.data_ptr(),
+                                            out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream(mask)), 'lfgc_codec_expand_f32')
+    return out
+
+
+def codec_kmeans(x: torch.Tensor, k: int = 256, iterations: int = 40) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(centres (k,) fp32 sorted, labels (n,) uint8) of the 1-D value set x.  Initial centres: Ward merging (host C++,
+    lfgc_codec_ward_init_host) of a sorted strided sample of at most 2^16 values; then Lloyd iterations over all values
+    on the GPU."""
+    x = _flat_f32(x)
+    n = x.numel()
+    if n < 1 or not 1 <= k <= 256:
+        raise ValueError('k-means needs at least one value and 1 <= k <= 256')
+    lib = _lib.load()
+    stride = max(1, -(-n // (1 << 16)))
+    sample = np.ascontiguousarray(torch.sort(x[::stride])[0].cpu().numpy())
+    init = np.empty(k, dtype=np.float32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    check(lib.lfgc_codec_ward_init_host(sample.ctypes.data_as(fp), sample.size, int(k), init.ctypes.data_as(fp)),
+          'lfgc_codec_ward_init_host')
+    centres = torch.from_numpy(init).to(x.device)
+    labels = torch.empty(n, dtype=torch.uint8, device=x.device)
+    nbytes = int(lib.lfgc_codec_kmeans_workspace_bytes(int(k)))
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=x.device)
+    check(lib.lfgc_codec_kmeans1d_f32(x.data_ptr(), n, int(k), centres.data_ptr(), labels.data_ptr(), int(iterations),
+                                      ws.data_ptr(), ws.numel() * 8, _stream(x)), 'lfgc_codec_kmeans1d_f32')
+    return centres, labels
+
+
+def codec_dequant(packed: torch.Tensor, bits: int, n: int, centres: torch.Tensor) -> torch.Tensor:
+    """(n,) fp32 = centres[label_i], labels `bits` wide, MSB first, in the uint8 stream `packed`."""
+    _require_hip(packed, centres)
+    if packed.dtype != torch.uint8:
+        raise ValueError('packed labels must be uint8')
+    centres = _f32c(centres)
+    if centres.numel() < (1 << int(bits)):
+        raise ValueError('codebook smaller than 2^bits')
+    out = torch.empty(int(n), dtype=torch.float32, device=packed.device)
+    check(_lib.load().lfgc_codec_dequant_f32(packed.contiguous().data_ptr(), packed.numel(), int(bits), int(n),
+                                             centres.data_ptr(), out.data_ptr(), _stream(packed)), 'lfgc_codec_dequant_f32')
+    return out
+
+
 # ---- ground truth / statistics -------------------------------------------------------------------------
 
 def gt_interp(p: torch.Tensor, f: torch.Tensor, min_bb, max_bb, res) -> torch.Tensor:

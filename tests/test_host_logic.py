@@ -244,3 +244,46 @@ def test_reference_factory_builds_our_module_after_module_swap():
     import subprocess
     r = subprocess.run([sys.executable, '-c', _SWAP_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=300)
     assert 'SWAP_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_ward_init_host_function():
+    """lfgc_codec_ward_init_host (host C++, no device): greedy adjacent Ward merging == a straightforward Python heap
+    version; n <= k returns the values themselves; unsorted input is rejected."""
+    import ctypes
+    import heapq
+    from latent_feature_grid_compression_amd import _lib
+    lib = _lib.load()
+    fp = ctypes.POINTER(ctypes.c_float)
+    rng = np.random.default_rng(8)
+    x = np.sort(np.concatenate([rng.standard_normal(700) * 0.05, rng.standard_normal(60) * 3])).astype(np.float32)
+    k = 64
+    out = np.empty(k, np.float32)
+    assert lib.lfgc_codec_ward_init_host(x.ctypes.data_as(fp), x.size, k, out.ctypes.data_as(fp)) == 0
+    cnt, su = [1.0] * x.size, [float(v) for v in x]
+    nxt = list(range(1, x.size)) + [-1]
+    prv = list(range(-1, x.size - 1))
+    alive, ver = [True] * x.size, [0] * x.size
+    cost = lambda a, b: cnt[a] * cnt[b] / (cnt[a] + cnt[b]) * (su[a] / cnt[a] - su[b] / cnt[b]) ** 2
+    heap = [(cost(i, i + 1), i, i + 1, 0, 0) for i in range(x.size - 1)]
+    heapq.heapify(heap)
+    n = x.size
+    while n > k:
+        c, a, b, va, vb = heapq.heappop(heap)
+        if not (alive[a] and alive[b]) or ver[a] != va or ver[b] != vb or nxt[a] != b:
+            continue
+        cnt[a] += cnt[b]; su[a] += su[b]; alive[b] = False; ver[a] += 1
+        nxt[a] = nxt[b]
+        if nxt[b] != -1:
+            prv[nxt[b]] = a
+            heapq.heappush(heap, (cost(a, nxt[a]), a, nxt[a], ver[a], ver[nxt[a]]))
+        if prv[a] != -1:
+            heapq.heappush(heap, (cost(prv[a], a), prv[a], a, ver[prv[a]], ver[a]))
+        n -= 1
+    ref = np.asarray([su[i] / cnt[i] for i in range(x.size) if alive[i]], np.float32)
+    assert np.array_equal(out, ref)
+    few = np.asarray([-1.0, 0.25, 0.5], np.float32)
+    out4 = np.empty(4, np.float32)
+    assert lib.lfgc_codec_ward_init_host(few.ctypes.data_as(fp), 3, 4, out4.ctypes.data_as(fp)) == 0
+    assert out4.tolist() == [-1.0, 0.25, 0.5, 0.5]
+    bad = np.asarray([1.0, 0.0], np.float32)
+    assert lib.lfgc_codec_ward_init_host(bad.ctypes.data_as(fp), 2, 1, out4.ctypes.data_as(fp)) == -2
