@@ -38,7 +38,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, den
 F16_MFMA_PEAK_TFLOPS = 2500.0      # same guide, dense BF16/F16 MFMA
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r1/*pmc_hbm*.json):
 # 2 x FETCH_SIZE (gfx950 correction for 16-B/lane reads) + WRITE_SIZE, per (workload, precision); None = not collected
-TRAFFIC_BYTES = {('headline', 'f16x2'): 396647584, ('headline', 'fp32'): 371994816}
+TRAFFIC_BYTES = {('headline', 'f16x2'): 375089621, ('headline', 'fp32'): 371095253}
 HBM_PEAK_GBS = 8000.0              # same guide, HBM3E spec
 
 WORKLOADS = {
