@@ -283,6 +283,13 @@ int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions
  * Ground-truth sampler and volume statistics
  * ---------------------------------------------------------------------------------------------- */
 
+/* Training positions for flat voxel indices drawn on the device (IndexDataset.__getitem__, data/IndexDataset.py:90-96
+ * with the index table of :56-57 and normalize_volume :7-8): raw (N,3) = integer lattice coordinates as fp32,
+ * norm (N,3) = scales * (2 * ((raw - min_idx) / (max_idx - min_idx)) - 1), the reference's fp32 operations (bit-exact).
+ *   flat device int64 (N), values in [0, X*Y*Z); res host int32[3]; min_idx / max_idx / scales host float[3]. */
+int lfgc_lattice_positions_f32(const int64_t* flat, int64_t n, const int32_t* res, const float* min_idx,
+                               const float* max_idx, const float* scales, float* raw, float* norm, lfgc_stream_t stream);
+
 /* trilinear_f_interpolation (data/Interpolation.py:8-44), bit-exact: fp32 lattice coordinates, fp64
  * alpha, fp32 lerps in x, y, z order without contraction.
  *   p device (N,3) raw positions; f device (X,Y,Z); min_bb/max_bb/res host float[3]; out device (N). */

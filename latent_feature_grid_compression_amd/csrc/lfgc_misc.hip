@@ -63,6 +63,31 @@ __device__ __forceinline__ void atomic_max_double(double* addr, double v) {
     }
 }
 
+// IndexDataset.__getitem__ (data/IndexDataset.py:90-96) for flat voxel indices drawn on the device: the row of the
+// (n_voxels, 3) index table (:56-57: integer lattice coordinates as fp32) and its normalisation
+// scales * ((maxN - minN) * ((raw - min) / (max - min)) + minN) with maxN = 1, minN = -1 (:7-8, :95), same fp32 operations.
+struct LatticeArgs {
+    const long long* flat; float* raw; float* norm; long long n;
+    int Y, Z;
+    float min0, min1, min2, max0, max1, max2, sc0, sc1, sc2;
+};
+
+__global__ __launch_bounds__(256) void lattice_positions_kernel(const LatticeArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const long long f = a.flat[i];
+    const long long yz = (long long)a.Y * a.Z;
+    const float r0 = (float)(f / yz), r1 = (float)((f / a.Z) % a.Y), r2 = (float)(f % a.Z);
+    auto nrm = [](float r, float mn, float mx, float sc) {
+        const float q = __fdiv_rn(__fsub_rn(r, mn), __fsub_rn(mx, mn));
+        return __fmul_rn(sc, __fadd_rn(__fmul_rn(2.0f, q), -1.0f));
+    };
+    a.raw[3 * i + 0] = r0; a.raw[3 * i + 1] = r1; a.raw[3 * i + 2] = r2;
+    a.norm[3 * i + 0] = nrm(r0, a.min0, a.max0, a.sc0);
+    a.norm[3 * i + 1] = nrm(r1, a.min1, a.max1, a.sc1);
+    a.norm[3 * i + 2] = nrm(r2, a.min2, a.max2, a.sc2);
+}
+
 // visualization/OutputToVTK.py:53-60 partial sums (fp64 accumulation).
 __global__ __launch_bounds__(256) void deviation_kernel(const float* pred, const float* gt, long long n, double* acc) {
     double sq = 0.0, ab = 0.0, mn = INFINITY, mx = -INFINITY;
@@ -266,6 +291,23 @@ extern "C" int lfgc_gt_interp_f32(const float* p, const float* f, const float* m
     a.max0 = max_bb[0]; a.max1 = max_bb[1]; a.max2 = max_bb[2];
     a.res0 = res[0]; a.res1 = res[1]; a.res2 = res[2];
     hipLaunchKernelGGL(gt_interp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_lattice_positions_f32(const int64_t* flat, int64_t n, const int32_t* res, const float* min_idx,
+                                          const float* max_idx, const float* scales, float* raw, float* norm,
+                                          lfgc_stream_t stream) {
+    if (!flat || !res || !min_idx || !max_idx || !scales || !raw || !norm) return LFGC_E_NULL;
+    if (n < 0 || res[0] < 1 || res[1] < 1 || res[2] < 1) return LFGC_E_SHAPE;
+    if (n == 0) return LFGC_OK;
+    LatticeArgs a;
+    a.flat = reinterpret_cast<const long long*>(flat); a.raw = raw; a.norm = norm; a.n = n;
+    a.Y = res[1]; a.Z = res[2];
+    a.min0 = min_idx[0]; a.min1 = min_idx[1]; a.min2 = min_idx[2];
+    a.max0 = max_idx[0]; a.max1 = max_idx[1]; a.max2 = max_idx[2];
+    a.sc0 = scales[0]; a.sc1 = scales[1]; a.sc2 = scales[2];
+    hipLaunchKernelGGL(lattice_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }

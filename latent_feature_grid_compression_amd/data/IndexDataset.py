@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import torch
 
+from .. import ops
+
 
 def normalize_volume(volume, minV, maxV, minN, maxN):
     return (maxN - minN) * ((volume - minV) / (maxV - minV)) + minN
@@ -48,6 +50,16 @@ class IndexDataset(torch.utils.data.Dataset):
                                 -1.0, 1.0)
         return raw, self.scales.to(raw.device).unsqueeze(0) * norm
 
+    def positions_from_flat(self, flat_idx: torch.Tensor):
+        """(raw, normalised) positions of flat voxel indices: one HIP kernel for device indices (bit-identical to the
+        two methods above, which are ~10 elementwise torch launches), the torch route for host indices."""
+        if flat_idx.is_cuda:
+            if getattr(self, '_host_bounds', None) is None:        # host copies: no device read inside a train step
+                self._host_bounds = (self.min_idx.cpu().tolist(), self.max_idx.cpu().tolist(), self.scales.cpu().tolist())
+            mn, mx, sc = self._host_bounds
+            return ops.lattice_positions(flat_idx, self.vol_res_touple, mn, mx, sc)
+        return self.positions_for(self.lattice_from_flat(flat_idx))
+
     def __len__(self):
         return self.n_voxels
 
@@ -73,6 +85,4 @@ class DeviceLatticeSampler:
 
     def sample(self, n: int, generator=None):
         flat = torch.randint(0, self.n_voxels, (int(n),), device=self.device, generator=generator)
-        raw = self.ds.lattice_from_flat(flat)
-        norm = normalize_volume(raw, self.min_idx.unsqueeze(0), self.max_idx.unsqueeze(0), -1.0, 1.0)
-        return raw, self.scales.unsqueeze(0) * norm
+        return self.ds.positions_from_flat(flat)

@@ -648,6 +648,20 @@ def gt_interp(p: torch.Tensor, f: torch.Tensor, min_bb, max_bb, res) -> torch.Te
     return out
 
 
+def lattice_positions(flat: torch.Tensor, res, min_idx, max_idx, scales) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(raw (N,3), norm (N,3)) for flat voxel indices on the device: lfgc_lattice_positions_f32."""
+    _require_hip(flat)
+    flat = flat.to(torch.int64).contiguous()
+    n = flat.numel()
+    raw = torch.empty((n, 3), dtype=torch.float32, device=flat.device)
+    norm = torch.empty((n, 3), dtype=torch.float32, device=flat.device)
+    f3 = lambda v: (ctypes.c_float * 3)(*[float(x) for x in (v.tolist() if hasattr(v, 'tolist') else v)])
+    r3 = (ctypes.c_int32 * 3)(*[int(x) for x in res])
+    check(_lib.load().lfgc_lattice_positions_f32(flat.data_ptr(), n, r3, f3(min_idx), f3(max_idx), f3(scales),
+                                                 raw.data_ptr(), norm.data_ptr(), _stream(flat)), 'lfgc_lattice_positions_f32')
+    return raw, norm
+
+
 def deviation_partial(pred: torch.Tensor, gt: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
     """acc = [sum sq, sum abs, min gt, max gt] (fp64, device)."""
     lib = _lib.load()

@@ -154,6 +154,12 @@ def test_device_lattice_sampler_matches_index_dataset(dev):
     flat = (r[:, 0] * shape[1] * shape[2] + r[:, 1] * shape[2] + r[:, 2]).long()
     _, ref_norm = ds.positions_for(ds.volume_indices[flat])
     assert torch.equal(norm.cpu(), ref_norm)
+    # the fused position kernel at the cfg-3 volume size, against the torch arithmetic on the same flat indices
+    big = IndexDataset((255, 255, 255), 16, build_index_table=False)
+    flat = torch.randint(0, big.n_voxels, (40000,), device=dev)
+    raw_k, norm_k = big.positions_from_flat(flat)
+    raw_t, norm_t = big.positions_for(big.lattice_from_flat(flat.cpu()))
+    assert torch.equal(raw_k.cpu(), raw_t) and torch.equal(norm_k.cpu(), norm_t)
 
 
 class _ScaleDrop(torch.nn.Module):

@@ -92,8 +92,7 @@ def main():
             g = torch.Generator(device=dev)
             g.manual_seed(3003 + i)
             flat = torch.randint(0, ds.n_voxels, (n,), device=dev, generator=g)
-        raw = ds.lattice_from_flat(flat)
-        _, norm = ds.positions_for(raw)
+        raw, norm = ds.positions_from_flat(flat)
         norm.requires_grad = not args.no_input_grad
         opt.zero_grad()
         pred = model(norm).squeeze(-1)
