@@ -296,6 +296,15 @@ int lfgc_lattice_positions_f32(const int64_t* flat, int64_t n, const int32_t* re
 int lfgc_gt_interp_f32(const float* p, const float* f, const float* min_bb, const float* max_bb,
                        const float* res, int64_t n, int X, int Y, int Z, float* out, lfgc_stream_t stream);
 
+/* Ground truth and MSE of a train step in one pass (training/training.py:107-109 + nn.MSELoss, :127, :201):
+ * gt as lfgc_gt_interp_f32 (bit-exact; also written to gt_out if non-NULL), loss (device float) = mean (pred - gt)^2 with
+ * fp64 accumulation in a fixed order, d_pred (N) = 2 (pred - gt) / N = d loss / d pred.
+ * workspace: lfgc_gt_mse_workspace_bytes(N) bytes. */
+int64_t lfgc_gt_mse_workspace_bytes(int64_t n);
+int lfgc_gt_mse_f32(const float* p, const float* f, const float* min_bb, const float* max_bb, const float* res,
+                    int64_t n, int X, int Y, int Z, const float* pred, float* gt_out, float* d_pred, float* loss,
+                    void* workspace, int64_t workspace_bytes, lfgc_stream_t stream);
+
 /* Partial sums for calculate_deviation_statistics (visualization/OutputToVTK.py:53-60):
  * acc[0] += sum (gt-pred)^2, acc[1] += sum |gt-pred|, acc[2] = min(acc[2], min gt), acc[3] = max(acc[3], max gt)
  * over n elements, fp64 accumulators on device (caller initialises acc = {0, 0, +inf, -inf}). */

@@ -74,6 +74,9 @@ SIGNATURES = {
                                   c_void_p, c_int64, c_void_p]),
     'lfgc_gt_interp_f32': (c_int, [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float),
                                    c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'lfgc_gt_mse_workspace_bytes': (c_int64, [c_int64]),
+    'lfgc_gt_mse_f32': (c_int, [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float), c_int64, c_int, c_int,
+                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'lfgc_lattice_positions_f32': (c_int, [c_void_p, c_int64, POINTER(c_int32), POINTER(c_float), POINTER(c_float),
                                            POINTER(c_float), c_void_p, c_void_p, c_void_p]),
     'lfgc_deviation_partial_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),

@@ -12,9 +12,7 @@ struct GtArgs {
 
 // data/Interpolation.py:8-44, same operation order, no contraction (file is built with -ffp-contract=off
 // and the arithmetic below uses the explicit round-to-nearest intrinsics).
-__global__ __launch_bounds__(256) void gt_interp_kernel(const GtArgs a) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
+__device__ __forceinline__ float gt_value(const GtArgs& a, long long i) {
     const float px = a.p[3 * i + 0], py = a.p[3 * i + 1], pz = a.p[3 * i + 2];
     // normalized_p = ((p - min_bb) / (max_bb - min_bb)) * (res - 1)
     const float nx = __fmul_rn(__fdiv_rn(__fsub_rn(px, a.min0), __fsub_rn(a.max0, a.min0)), __fsub_rn(a.res0, 1.0f));
@@ -41,7 +39,44 @@ __global__ __launch_bounds__(256) void gt_interp_kernel(const GtArgs a) {
     const float x_y1z1 = __fadd_rn(__fmul_rn(bx, F(X0, Y1, Z1)), __fmul_rn(ax, F(X1, Y1, Z1)));
     const float y_z0 = __fadd_rn(__fmul_rn(by, x_y0z0), __fmul_rn(ay, x_y1z0));
     const float y_z1 = __fadd_rn(__fmul_rn(by, x_y0z1), __fmul_rn(ay, x_y1z1));
-    a.out[i] = __fadd_rn(__fmul_rn(bz, y_z0), __fmul_rn(az, y_z1));
+    return __fadd_rn(__fmul_rn(bz, y_z0), __fmul_rn(az, y_z1));
+}
+
+__global__ __launch_bounds__(256) void gt_interp_kernel(const GtArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n) a.out[i] = gt_value(a, i);
+}
+
+// Ground truth + MSE of a train step in one pass (training/training.py:107-109 + :127 with nn.MSELoss): gt as above,
+// diff = pred - gt, d_pred = (2/N) diff (the gradient of the mean), per-workgroup fp64 partial of sum diff^2; a second
+// one-workgroup kernel folds the partials in a fixed order into loss = sum / N.
+__global__ __launch_bounds__(256) void gt_mse_kernel(const GtArgs a, const float* __restrict__ pred, float* __restrict__ d_pred,
+                                                     double* __restrict__ partials, float two_over_n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    double sq = 0.0;
+    if (i < a.n) {
+        const float g = gt_value(a, i);
+        const float d = __fsub_rn(pred[i], g);
+        if (a.out) a.out[i] = g;
+        d_pred[i] = __fmul_rn(d, two_over_n);
+        sq = (double)d * (double)d;
+    }
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void mse_fold_kernel(const double* __restrict__ partials, int nparts, double inv_n,
+                                                       float* __restrict__ loss) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nparts; b += 256) acc += partials[b];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = (float)(((s[0] + s[1]) + (s[2] + s[3])) * inv_n);
 }
 
 __device__ __forceinline__ void atomic_min_double(double* addr, double v) {
@@ -291,6 +326,30 @@ extern "C" int lfgc_gt_interp_f32(const float* p, const float* f, const float* m
     a.max0 = max_bb[0]; a.max1 = max_bb[1]; a.max2 = max_bb[2];
     a.res0 = res[0]; a.res1 = res[1]; a.res2 = res[2];
     hipLaunchKernelGGL(gt_interp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int64_t lfgc_gt_mse_workspace_bytes(int64_t n) { return n < 1 ? 8 : ((n + 255) / 256) * 8; }
+
+extern "C" int lfgc_gt_mse_f32(const float* p, const float* f, const float* min_bb, const float* max_bb, const float* res,
+                               int64_t n, int X, int Y, int Z, const float* pred, float* gt_out, float* d_pred, float* loss,
+                               void* workspace, int64_t workspace_bytes, lfgc_stream_t stream) {
+    if (!p || !f || !min_bb || !max_bb || !res || !pred || !d_pred || !loss || !workspace) return LFGC_E_NULL;
+    if (n < 1 || X < 1 || Y < 1 || Z < 1) return LFGC_E_SHAPE;
+    if (workspace_bytes < lfgc_gt_mse_workspace_bytes(n)) return LFGC_E_WORKSPACE;
+    GtArgs a;
+    a.p = p; a.f = f; a.out = gt_out; a.n = n; a.X = X; a.Y = Y; a.Z = Z;
+    a.min0 = min_bb[0]; a.min1 = min_bb[1]; a.min2 = min_bb[2];
+    a.max0 = max_bb[0]; a.max1 = max_bb[1]; a.max2 = max_bb[2];
+    a.res0 = res[0]; a.res1 = res[1]; a.res2 = res[2];
+    const long long blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
+    double* partials = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(gt_mse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, pred, d_pred, partials,
+                       (float)(2.0 / (double)n));
+    LFGC_HIP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mse_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)blocks, 1.0 / (double)n, loss);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }

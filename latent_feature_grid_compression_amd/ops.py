@@ -648,6 +648,41 @@ def gt_interp(p: torch.Tensor, f: torch.Tensor, min_bb, max_bb, res) -> torch.Te
     return out
 
 
+class GtMseLossFn(torch.autograd.Function):
+    """loss = MSELoss()(pred, trilinear_f_interpolation(p, f, ...)) as one node: ground truth, squared error and the
+    gradient of the mean in one kernel (+ a one-workgroup fold).  apply(pred (N,), p (N,3), f (X,Y,Z), min_bb, max_bb, res)
+    with the three bounds as host sequences of 3 floats."""
+
+    @staticmethod
+    def forward(ctx, pred, p, f, min_bb, max_bb, res):
+        lib = _lib.load()
+        _require_hip(pred, p, f)
+        pred_c, p, f = _f32c(pred.detach()).reshape(-1), _f32c(p.detach()), _f32c(f.detach())
+        n = pred_c.numel()
+        if p.shape != (n, 3):
+            raise ValueError('positions %s do not match %d predictions' % (tuple(p.shape), n))
+        arr = lambda v: (ctypes.c_float * 3)(*[float(x) for x in (v.tolist() if hasattr(v, 'tolist') else v)])
+        d_pred = torch.empty_like(pred_c)
+        loss = torch.empty((), dtype=torch.float32, device=pred_c.device)
+        ws = torch.empty(int(lib.lfgc_gt_mse_workspace_bytes(n)) // 8, dtype=torch.float64, device=pred_c.device)
+        X, Y, Z = f.shape
+        check(lib.lfgc_gt_mse_f32(p.data_ptr(), f.data_ptr(), arr(min_bb), arr(max_bb), arr(res), n, X, Y, Z,
+                                  pred_c.data_ptr(), None, d_pred.data_ptr(), loss.data_ptr(), ws.data_ptr(),
+                                  ws.numel() * 8, _stream(pred_c)), 'lfgc_gt_mse_f32')
+        ctx.save_for_backward(d_pred)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_pred,) = ctx.saved_tensors
+        return (d_pred * g).view(ctx.shape), None, None, None, None, None
+
+
+def gt_mse_loss(pred, p, f, min_bb, max_bb, res) -> torch.Tensor:
+    return GtMseLossFn.apply(pred, p, f, min_bb, max_bb, res)
+
+
 def lattice_positions(flat: torch.Tensor, res, min_idx, max_idx, scales) -> Tuple[torch.Tensor, torch.Tensor]:
     """(raw (N,3), norm (N,3)) for flat voxel indices on the device: lfgc_lattice_positions_f32."""
     _require_hip(flat)

@@ -24,12 +24,13 @@ def main():
     ap.add_argument('--no-input-grad', action='store_true')
     ap.add_argument('--foreach-adam', action='store_true', help="torch's default (foreach) Adam instead of fused=True")
     ap.add_argument('--graph', action='store_true', help='capture one train step in a HIP graph and replay it')
+    ap.add_argument('--torch-loss', action='store_true', help='GT gather + torch MSELoss instead of the fused GT+MSE kernel')
     ap.add_argument('--drop-type', default='', choices=['', 'smallify', 'masked_straight_through', 'variational'],
                     help='pruning layers on the coefficients + their loss (the reference CLI default is smallify)')
     ap.add_argument('--unfused-drop', action='store_true',
                     help='comparison: apply the drop factors and penalties with torch ops instead of the fused HIP kernels')
     args = ap.parse_args()
-    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_f_interpolation
+    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_f_interpolation, trilinear_mse_loss
     from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
     dev = torch.device('cuda:0')
     w = bench.WORKLOADS['headline']
@@ -83,6 +84,7 @@ def main():
     loss_fn = torch.nn.MSELoss()
     n = 2048 * 16
     mn, mx, rs = ds.min_idx.clone(), ds.max_idx.clone(), ds.vol_res.clone()      # host copies for the GT sampler's bounds
+    mn_h, mx_h, rs_h = mn.tolist(), mx.tolist(), rs.tolist()
     ds.min_idx, ds.max_idx, ds.scales = ds.min_idx.to(dev), ds.max_idx.to(dev), ds.scales.to(dev)   # no H2D inside the step
 
     def step(i, backward=True):
@@ -96,8 +98,11 @@ def main():
         norm.requires_grad = not args.no_input_grad
         opt.zero_grad()
         pred = model(norm).squeeze(-1)
-        gt = trilinear_f_interpolation(raw, vol, mn, mx, rs)
-        loss = loss_fn(pred, gt) if drop_loss is None else drop_loss(pred, gt)
+        if drop_loss is None and not args.torch_loss:
+            loss = trilinear_mse_loss(pred, raw, vol, mn_h, mx_h, rs_h)
+        else:
+            gt = trilinear_f_interpolation(raw, vol, mn, mx, rs)
+            loss = loss_fn(pred, gt) if drop_loss is None else drop_loss(pred, gt)
         if backward:
             loss.backward()
             opt.step()
