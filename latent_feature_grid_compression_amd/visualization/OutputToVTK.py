@@ -125,7 +125,8 @@ def slab_partition(res_x: int, world_size: int, tiled_res: int = 32) -> List[Tup
 
 def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=None,
                                slab_fn: Optional[Callable[[int, int, torch.Tensor], None]] = None,
-                               device: Optional[torch.device] = None, chunks: Optional[int] = None) -> torch.Tensor:
+                               device: Optional[torch.device] = None, chunks: Optional[int] = None,
+                               always_gather: bool = False) -> torch.Tensor:
     """Every rank evaluates its x-slab of tiles and the slabs are assembled with all-gathers; returns the full
     (X,Y,Z) volume on every rank.
 
@@ -148,7 +149,7 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
         def slab_fn(b, e, out_view):
             field_from_net_fused(dataset, net, b, e, tiled_res, out=out_view)
     b, e = parts[rank]
-    if world == 1:
+    if world == 1 and not always_gather:     # always_gather: run the collective path even alone (RCCL smoke test)
         out = torch.empty(res, dtype=torch.float32, device=device)
         if e > b:
             slab_fn(b, e, out[b:e])

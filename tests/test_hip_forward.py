@@ -451,3 +451,25 @@ def test_headline_volume_invariants(dev):
         with torch.no_grad():
             yt = m(tp.unsqueeze(0).to(dev)).squeeze(0).squeeze(-1)
         assert rel_err(full[b[0]:b[1], b[2]:b[3], b[4]:b[5]].cpu().numpy(), yt.cpu().numpy()) <= 2e-6
+
+
+def test_sharded_driver_over_rccl_single_rank(dev):
+    """The chunked all-gather path of reconstruct_volume_sharded through RCCL itself (backend 'nccl'), one rank: the
+    multi-rank logic is covered by the gloo tests on CPU, this checks the collective calls on device tensors."""
+    import torch.distributed as dist
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    from latent_feature_grid_compression_amd.visualization import OutputToVTK as V
+    if dist.is_initialized():
+        pytest.skip('a process group already exists')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        m, _ = build_synth(8, 16, 32, 2, seed=77, dev=dev)
+        m.eval()
+        ds = IndexDataset((70, 40, 33), 16, build_index_table=False)
+        ref = V.field_from_net_fused(ds, m)
+        got = V.reconstruct_volume_sharded(ds, m, chunks=3, always_gather=True)
+        assert torch.equal(got, ref)
+    finally:
+        dist.destroy_process_group()
