@@ -70,8 +70,9 @@ def build_model(w, seed, device):
     return model.to(device).eval()
 
 
-def cpu_baseline(model, w, budget_s=20.0):
-    """Oracle (op-for-op torch restatement of the reference) on the host cores, bounded sample of the workload."""
+def cpu_baseline(model, w, budget_s=20.0, hip_volume=None):
+    """Oracle (op-for-op torch restatement of the reference) on the host cores, bounded sample of the workload.  With
+    ``hip_volume`` (the volume the timed HIP path produced) the oracle's tiles also serve as the in-run parity check."""
     from oracle import ref_torch as R
     # the GPU box gives one-GPU jobs a 16-CPU share of its 256 hardware threads; torch oversubscribed to 256 threads
     # runs this path 70x slower (tools/microbench/cpu_threads.py: 4..32 threads all give ~0.5 Msamples/s)
@@ -90,6 +91,7 @@ def cpu_baseline(model, w, budget_s=20.0):
         # warm-up tile
         R.forward_from_grid(dense, weights, biases, R.tile_positions(ds, tiles[0]).reshape(-1, 3), 2)
         n_samples, n_tiles, t_fwd = 0, 0, 0.0
+        max_err, max_ref, sq_err, gt_min, gt_max = 0.0, 0.0, 0.0, float('inf'), float('-inf')
         for b in tiles:
             pos = R.tile_positions(ds, b).reshape(-1, 3)
             t0 = time.perf_counter()
@@ -97,9 +99,24 @@ def cpu_baseline(model, w, budget_s=20.0):
             t_fwd += time.perf_counter() - t0
             n_samples += pos.shape[0]
             n_tiles += 1
+            if hip_volume is not None:
+                x0, x1, y0, y1, z0, z1 = b
+                mine = hip_volume[x0:x1, y0:y1, z0:z1].cpu().reshape(-1).double()
+                ref = y.reshape(-1).double()
+                max_err = max(max_err, float((mine - ref).abs().max()))
+                max_ref = max(max_ref, float(ref.abs().max()))
+                sq_err += float(((mine - ref) ** 2).sum())
+                gt_min, gt_max = min(gt_min, float(ref.min())), max(gt_max, float(ref.max()))
             if t_fwd > budget_s or n_tiles >= 64:
                 break
+    parity = None
+    if hip_volume is not None:
+        mse = sq_err / n_samples
+        parity = {'max_rel_err_vs_oracle': max_err / max_ref, 'tolerance': 1e-5,
+                  'psnr_of_hip_vs_oracle_dB': (10.0 * math.log10((gt_max - gt_min) ** 2 / mse)) if mse > 0 else float('inf'),
+                  'samples': n_samples}
     return {
+        'parity': parity,
         'value': n_samples / t_fwd / 1e6, 'unit': 'Msamples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
         'sample': '%d tiles of 32^3 (%d samples) of the same lattice, grid decoded once (%.3f s, not included); '
                   'with the reference\'s per-tile decode: %.4f Msamples/s'
@@ -229,7 +246,22 @@ def main():
                                              'peak_GBs': HBM_PEAK_GBS, 'frac': hbm_alg_gbs / HBM_PEAK_GBS}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(model, w)
+            out['cpu_baseline'] = cpu_baseline(model, w, hip_volume=vol)
+            if split:
+                # the same pass with the exact build (v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain): its rate and
+                # how far the default build's volume is from it
+                model.precision = 'fp32'
+                for _ in range(2):
+                    v32 = one_step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    v32 = one_step()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 5
+                out['exact_fp32_build'] = {'value': total_samples / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt * 1e3,
+                                           'max_rel_diff_of_default_build': float((vol - v32).abs().max() / v32.abs().max())}
+                model.precision = 'f16x2'
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
