@@ -233,7 +233,8 @@ typedef struct lfgc_positions {
     /* pos == NULL: full-volume lattice of visualization/OutputToVTK.py:11-37 (field_from_net), x-slab
      * [x_begin, x_end) of a (res0,res1,res2) volume cut into tiles of `tile` voxels; sample order =
      * row-major (x,y,z) of the slab, i.e. out[(x-x_begin)*res1*res2 + y*res2 + z].  Positions are formed
-     * per tile exactly as the reference does (linspace(start,end,n) -> *2-1 -> *scales, fp32). */
+     * per tile exactly as the reference does (linspace(start,end,n) -> *2-1 -> *scales, fp32) from the ABSOLUTE voxel
+     * index, so a slab may start and end anywhere, not only on tile boundaries. */
     int32_t res[3];
     int32_t x_begin, x_end;
     int32_t tile;            /* reference: 32 */

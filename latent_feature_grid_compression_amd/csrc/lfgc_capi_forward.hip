@@ -38,7 +38,6 @@ int lfgc_fill_positions(const lfgc_positions* ps, LfgcFwdArgs* a, long long* n_o
     }
     if (ps->res[0] < 2 || ps->res[1] < 2 || ps->res[2] < 2 || ps->tile < 1) return LFGC_E_SHAPE;
     if (ps->x_begin < 0 || ps->x_end > ps->res[0] || ps->x_end < ps->x_begin) return LFGC_E_SHAPE;
-    if (ps->x_begin % ps->tile != 0) return LFGC_E_SHAPE;      // slabs start on a tile boundary
     a->pos = nullptr;
     a->res0 = ps->res[0]; a->res1 = ps->res[1]; a->res2 = ps->res[2];
     a->x_begin = ps->x_begin; a->tile = ps->tile;

@@ -130,9 +130,10 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
     """Every rank evaluates its x-slab of tiles and the slabs are assembled with all-gathers; returns the full
     (X,Y,Z) volume on every rank.
 
-    The slab is cut into ``chunks`` pieces of whole tile planes (default: one per tile plane, at most 4); each piece is
-    gathered with its own ``all_gather_into_tensor`` issued asynchronously right after the piece's kernel launch, so
-    the collective of piece c (RCCL's stream, xGMI) runs under the compute of piece c+1.  ``chunks=1`` = one gather.
+    The slab is cut into ``chunks`` pieces (default 4) of x-rows -- whole tile planes while there are enough of them,
+    multiples of 8 rows otherwise (8 ranks on 256^3 own one tile plane each) --; each piece is gathered with its own
+    ``all_gather_into_tensor`` issued asynchronously right after the piece's kernel launch, so the collective of piece
+    c (RCCL's stream, xGMI) runs under the compute of piece c+1.  ``chunks=1`` = one gather.
 
     ``slab_fn(x_begin, x_end, out_view)`` fills ``out_view`` ((x_end-x_begin, Y, Z)); default = the fused HIP
     forward of ``net``.  (The CPU/gloo tests inject a stub here: the HIP path itself has no CPU form.)"""
@@ -155,9 +156,11 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
             slab_fn(b, e, out[b:e])
         return out
     # piece boundaries relative to the slab start, on tile planes, identical on every rank (from max_x)
-    planes = (max_x + tiled_res - 1) // tiled_res
-    n_chunks = max(1, min(planes, 4 if chunks is None else int(chunks)))
-    cuts = [min(((c * planes) // n_chunks) * tiled_res, max_x) for c in range(n_chunks + 1)]
+    want = 4 if chunks is None else max(1, int(chunks))
+    unit = tiled_res if (max_x + tiled_res - 1) // tiled_res >= want else 8
+    units = (max_x + unit - 1) // unit
+    n_chunks = max(1, min(units, want))
+    cuts = [min(((c * units) // n_chunks) * unit, max_x) for c in range(n_chunks + 1)]
     cuts[-1] = max_x
     bufs, works = [], []
     for c in range(n_chunks):

@@ -471,5 +471,11 @@ def test_sharded_driver_over_rccl_single_rank(dev):
         ref = V.field_from_net_fused(ds, m)
         got = V.reconstruct_volume_sharded(ds, m, chunks=3, always_gather=True)
         assert torch.equal(got, ref)
+        # pieces finer than a tile plane (what 8 ranks on 256^3 use): slabs may start anywhere
+        got = V.reconstruct_volume_sharded(IndexDataset((31, 40, 33), 16, build_index_table=False), m, chunks=4,
+                                           always_gather=True)
+        assert torch.equal(got, V.field_from_net_fused(IndexDataset((31, 40, 33), 16, build_index_table=False), m))
+        parts = [V.field_from_net_fused(ds, m, b, e) for b, e in ((0, 5), (5, 37), (37, 64), (64, 70))]
+        assert torch.equal(torch.cat(parts, 0), ref)
     finally:
         dist.destroy_process_group()

@@ -193,7 +193,8 @@ def _gloo_worker(rank, world, port, res, out_dir, chunks=None):
 
 
 @pytest.mark.parametrize('res,world,chunks', [((70, 9, 11), 2, None), ((33, 5, 4), 2, None), ((64, 6, 6), 2, 1),
-                                              ((200, 4, 5), 2, 3), ((255, 3, 3), 3, None)])
+                                              ((200, 4, 5), 2, 3), ((255, 3, 3), 3, None),
+                                              ((64, 6, 6), 2, None), ((128, 3, 3), 4, None)])   # pieces finer than a tile plane
 def test_sharded_reconstruction_gloo(tmp_path, res, world, chunks):
     port = _free_port()
     mp.spawn(_gloo_worker, args=(world, port, res, str(tmp_path), chunks), nprocs=world, join=True)
