@@ -165,8 +165,10 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
     bufs, works = [], []
     for c in range(n_chunks):
         lo, hi = cuts[c], cuts[c + 1]
-        mine = torch.zeros((hi - lo, res[1], res[2]), dtype=torch.float32, device=device)
+        mine = torch.empty((hi - lo, res[1], res[2]), dtype=torch.float32, device=device)
         xb, xe = min(b + lo, e), min(b + hi, e)
+        if xe - xb < hi - lo:
+            mine[xe - xb:].zero_()               # rows past this rank's (shorter) slab: padding of the equal-size gather
         if xe > xb:
             slab_fn(xb, xe, mine[:xe - xb])
         gathered = torch.empty((world * (hi - lo), res[1], res[2]), dtype=torch.float32, device=device)
