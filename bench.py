@@ -115,8 +115,17 @@ def cpu_baseline(model, w, budget_s=20.0, hip_volume=None):
         parity = {'max_rel_err_vs_oracle': max_err / max_ref, 'tolerance': 1e-5,
                   'psnr_of_hip_vs_oracle_dB': (10.0 * math.log10((gt_max - gt_min) ** 2 / mse)) if mse > 0 else float('inf'),
                   'samples': n_samples}
+    cpu_model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    cpu_model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
-        'parity': parity,
+        'parity': parity, 'cpu_model': cpu_model, 'host_threads_visible': os.cpu_count(),
         'value': n_samples / t_fwd / 1e6, 'unit': 'Msamples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
         'sample': '%d tiles of 32^3 (%d samples) of the same lattice, grid decoded once (%.3f s, not included); '
                   'with the reference\'s per-tile decode: %.4f Msamples/s'
