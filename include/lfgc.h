@@ -246,9 +246,17 @@ typedef struct lfgc_positions {
  *   LFGC_PRECISION_F16X2  every fp32 operand carried as an f16 pair hi + lo (22-24 significant bits), three
  *                         v_mfma_f32_32x32x16_f16 per product block with fp32 accumulation: same error level as the
  *                         fp32 build against the reference (fp32 summation order dominates), ~3x the throughput.
- *                         Needs |activations| < 65504. */
+ *                         Needs |activations| < 65504.
+ *   LFGC_PRECISION_F16    REDUCED precision (opt-in, never the default; does not meet the 1e-5 parity bound): weights and
+ *                         activations of the layer GEMMs rounded to f16 (weights pre-scaled per layer as above), ONE
+ *                         v_mfma_f32_32x32x16_f16 per product block, fp32 accumulation, fp32 master parameters, fp32
+ *                         everything else.  This package's form of the "bf16 compute" BASELINE config 3 names (the
+ *                         reference has no reduced-precision path): f16 rather than bf16 because it runs at the same
+ *                         MFMA rate with 3 more mantissa bits and the ranges are known (scaled weights, activations
+ *                         < 65504, gradients rescaled per tile).  Error ~1e-3 of the output range. */
 #define LFGC_PRECISION_F32 0
 #define LFGC_PRECISION_F16X2 1
+#define LFGC_PRECISION_F16 2
 
 /* forward().  Replaces model/Feature_Grid_Model.py:62-78 (everything after decode_volume):
  * F.grid_sample(bilinear, align_corners=False, zeros) of the dense grid, Embedder.embed

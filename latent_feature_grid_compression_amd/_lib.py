@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LFGC_LIB_PATH') or os.path.join(PKG_DIR, 'liblfgc.so')   # override: diagnostics builds only
 LFGC_MAX_LAYERS = 8
-PRECISION = {'fp32': 0, 'f16x2': 1}
+PRECISION = {'fp32': 0, 'f16x2': 1, 'f16': 2}
 
 
 class LfgcError(RuntimeError):

@@ -73,16 +73,18 @@ __device__ __forceinline__ void lfgc_snake_bwd(const float* __restrict__ slot, c
 // t computes, one barrier per step); the scatter staging aliases the ring slot that has just been consumed.
 // acc += Wt_tile . dA for one 32-row tile with f16-split operands (three MFMAs per 16-wide k-step); `arow` = LDS
 // address of (row 32m + lane&31, lane half's 32 bytes of k-step 0).
-template <int KS16>
+template <int KS16, bool SPLIT>
 __device__ __forceinline__ f32x16 lfgc_mfma_tile16(const float* __restrict__ arow, const h16x8 (&Fhi)[KS16],
                                                    const h16x8 (&Flo)[KS16], f32x16 acc) {
 #pragma unroll
     for (int ks = 0; ks < KS16; ++ks) {
         const h16x8 whi = *reinterpret_cast<const h16x8*>(arow + 16 * ks);
-        const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, Fhi[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Flo[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Fhi[ks], acc, 0, 0, 0);
+        if (SPLIT) {
+            const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, Fhi[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Flo[ks], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Fhi[ks], acc, 0, 0, 0);   // SPLIT = false: the single product
     }
     return acc;
 }
@@ -104,21 +106,25 @@ __device__ __forceinline__ float lfgc_tile_pow2_scale(const float (&v)[NV], floa
     return __int_as_float((127 + k) << 23);
 }
 
-template <int NF16>
+template <int NF16, bool SPLIT>
 __device__ __forceinline__ void lfgc_split_scaled(const float* __restrict__ v, float sc, h16x8 (&Fhi)[NF16], h16x8 (&Flo)[NF16]) {
 #pragma unroll
     for (int f = 0; f < NF16; ++f) {
         float t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) t[u] = v[8 * f + u] * sc;
-        lfgc_split8(t, Fhi[f], Flo[f]);
+        if (SPLIT) lfgc_split8(t, Fhi[f], Flo[f]);
+        else lfgc_cvt8(t, Fhi[f]);
     }
 }
 
-// H16 = false: exact f32 MFMA chain.  H16 = true: the chain's GEMMs run f16-split like the default forward build
-// (dA carried as f16 hi+lo fragments, transposed weight images pre-split and scaled; fp32 accumulate, scaled back).
-template <int CH, int MT, int NF, int WAVES, bool H16>
+// PREC (the C-ABI precision code) 0: exact f32 MFMA chain.  1: the chain's GEMMs run f16-split like the default forward
+// build (dA carried as f16 hi+lo fragments, transposed weight images pre-split and scaled; fp32 accumulate, scaled
+// back).  2: reduced precision, the hi halves only (one f16 product).
+template <int CH, int MT, int NF, int WAVES, int PREC>
 __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const LfgcBwdArgs a) {
+    constexpr bool H16 = PREC != 0;
+    constexpr bool SPLIT = PREC == 1;
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
     constexpr int K0P = CH + EP;
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 h16x8 Fhi[2 * MT], Flo[2 * MT];
                 float isc;
                 const float sc = lfgc_tile_pow2_scale<16 * MT>(dA, isc);
-                lfgc_split_scaled<2 * MT>(dA, sc, Fhi, Flo);
+                lfgc_split_scaled<2 * MT, SPLIT>(dA, sc, Fhi, Flo);
                 const float* s_row = acquire(l) + j * ST + 8 * hh;
                 const float is = s_inv[l] * isc;
 #pragma unroll
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    acc = lfgc_mfma_tile16<2 * MT>(s_row + 32 * m * ST, Fhi, Flo, acc);
+                    acc = lfgc_mfma_tile16<2 * MT, SPLIT>(s_row + 32 * m * ST, Fhi, Flo, acc);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dH[16 * m + r] = acc[r] * is;
                 }
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             float isc = 1.0f;
             if (H16) {
                 const float sc = lfgc_tile_pow2_scale<16 * MT>(dA, isc);
-                lfgc_split_scaled<2 * MT>(dA, sc, Fhi, Flo);
+                lfgc_split_scaled<2 * MT, SPLIT>(dA, sc, Fhi, Flo);
             }
             const float* s_row = acquire(0) + j * ST + (H16 ? 8 : 4) * hh;
             const float is = H16 ? s_inv[0] * isc : 1.0f;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    if (H16) acc = lfgc_mfma_tile16<2 * MT>(s_row + 32 * m * ST, Fhi, Flo, acc);
+                    if (H16) acc = lfgc_mfma_tile16<2 * MT, SPLIT>(s_row + 32 * m * ST, Fhi, Flo, acc);
                     else acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dX[16 * m + r] = acc[r] * is;
@@ -659,9 +665,9 @@ static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcR
     if (q == 0 && idx < total) *dst = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
 }
 
-template <int CH, int MT, int NF, int WAVES, bool H16>
+template <int CH, int MT, int NF, int WAVES, int PREC>
 static int lfgc_launch_bwd_data(const LfgcBwdArgs& a, int lds_bytes, int grid_data, hipStream_t stream) {
-    auto kd = lfgc_bwd_data_kernel<CH, MT, NF, WAVES, H16>;
+    auto kd = lfgc_bwd_data_kernel<CH, MT, NF, WAVES, PREC>;
     static int lds_limit_set = 0;
     if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd),
@@ -679,10 +685,13 @@ template <int CH, int MT, int NF>
 static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int waves, int h16, int lds_bytes, int grid_data,
                            int grid_w, hipStream_t stream) {
     int rc;
-    if (h16) rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, true>(a, lds_bytes, grid_data, stream)
-                             : lfgc_launch_bwd_data<CH, MT, NF, 4, true>(a, lds_bytes, grid_data, stream);
-    else rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, false>(a, lds_bytes, grid_data, stream)
-                         : lfgc_launch_bwd_data<CH, MT, NF, 4, false>(a, lds_bytes, grid_data, stream);
+    // h16 = the C-ABI precision code: 0 exact f32 MFMA chain, 1 f16 hi/lo split, 2 single f16 product
+    if (h16 == 1) rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, 1>(a, lds_bytes, grid_data, stream)
+                                  : lfgc_launch_bwd_data<CH, MT, NF, 4, 1>(a, lds_bytes, grid_data, stream);
+    else if (h16 == 2) rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, 2>(a, lds_bytes, grid_data, stream)
+                                       : lfgc_launch_bwd_data<CH, MT, NF, 4, 2>(a, lds_bytes, grid_data, stream);
+    else rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, 0>(a, lds_bytes, grid_data, stream)
+                         : lfgc_launch_bwd_data<CH, MT, NF, 4, 0>(a, lds_bytes, grid_data, stream);
     if (rc != LFGC_OK) return rc;
     {
         constexpr int K0R_ = (CH + (3 + 6 * NF + 7) / 8 * 8 + 31) / 32 * 32;

@@ -43,7 +43,7 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     if (!desc || !positions || !grid_cl || !packed || !stash || !d_out || !d_grid_cl || !d_weights || !d_biases)
         return LFGC_E_NULL;
     if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
-    if (precision != LFGC_PRECISION_F32 && precision != LFGC_PRECISION_F16X2) return LFGC_E_UNSUPPORTED;
+    if (precision != LFGC_PRECISION_F32 && precision != LFGC_PRECISION_F16X2 && precision != LFGC_PRECISION_F16) return LFGC_E_UNSUPPORTED;
     if (!positions->pos) return LFGC_E_NULL;            // backward runs on explicit positions only
     if (positions->n < 0 || D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
     if ((((uintptr_t)grid_cl) | ((uintptr_t)packed) | ((uintptr_t)stash) | ((uintptr_t)d_grid_cl) | ((uintptr_t)workspace)) & 15)
@@ -99,10 +99,10 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
 
     int rc;
     switch (p.CH) {
-        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, waves, precision == LFGC_PRECISION_F16X2, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
         default: return LFGC_E_UNSUPPORTED;
     }
     if (rc != LFGC_OK) return rc;

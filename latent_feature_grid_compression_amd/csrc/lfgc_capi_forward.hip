@@ -56,7 +56,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     if (!desc || !positions || !grid_cl || !packed || !out) return LFGC_E_NULL;
     if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
     if (D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
-    if (precision != LFGC_PRECISION_F32 && precision != LFGC_PRECISION_F16X2) return LFGC_E_UNSUPPORTED;
+    if (precision != LFGC_PRECISION_F32 && precision != LFGC_PRECISION_F16X2 && precision != LFGC_PRECISION_F16) return LFGC_E_UNSUPPORTED;
     if ((((uintptr_t)grid_cl) | ((uintptr_t)packed)) & 15) return LFGC_E_ALIGN;
     const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
     LfgcFwdArgs a;
@@ -70,7 +70,8 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     // LDS: [Wf | bf] + every layer block (resident: 4-wave workgroups, two per CU) or a 2-deep ring of the
     // largest block (streamed: 8-wave workgroups, one per CU).  The stash is laid out per 32-sample tile in
     // whole 128-sample groups either way (lfgc_stash_bytes), so both builds write the same format.
-    const bool h16 = precision == LFGC_PRECISION_F16X2;
+    const bool h16 = precision != LFGC_PRECISION_F32;
+    a.single = precision == LFGC_PRECISION_F16 ? 1 : 0;
     const int all_blocks = h16 ? p.blkh0 + (p.L - 1) * p.blkh1 : p.off_final;
     const int max_block = h16 ? (p.blkh0 > p.blkh1 ? p.blkh0 : p.blkh1) : (p.blk0 > p.blk1 ? p.blk0 : p.blk1);
     const int fixed = p.HP + 4 + (h16 ? 16 : 0);        // [Wf | bf] (+ per-layer scales)

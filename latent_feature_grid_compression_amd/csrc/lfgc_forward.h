@@ -43,6 +43,7 @@ struct LfgcFwdArgs {
     long long nbatches;        // ceil(N / (32 * waves per workgroup))
     int waves;                 // waves per workgroup of the chosen build (4 or 8)
     int coord_table;           // lattice mode: per-axis coordinate tables fit LDS (res0+res1+res2 floats)
+    int single;                // f16 builds: 1 = single product W_hi.h_hi (LFGC_PRECISION_F16), 0 = hi/lo split
 };
 
 // Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile

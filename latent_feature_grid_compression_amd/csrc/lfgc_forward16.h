@@ -42,9 +42,22 @@ __device__ __forceinline__ void lfgc_split8(const float* __restrict__ x, h16x8& 
     lo = __builtin_bit_cast(h16x8, lp);
 }
 
+// Reduced-precision build (LFGC_PRECISION_F16): the hi half only, one packed conversion per pair.
+__device__ __forceinline__ void lfgc_cvt8(const float* __restrict__ x, h16x8& hi) {
+    u32x4 hp;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        unsigned h;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x[2 * t]), "v"(x[2 * t + 1]));
+        hp[t] = h;
+    }
+    hi = __builtin_bit_cast(h16x8, hp);
+}
+
 // One hidden layer on a 32-sample tile.  LAST = false: outputs the next layer's fragments; LAST = true: folds the
 // final Linear (H -> 1) in and returns this lane's partial dot product through `ydot`.
-template <int KS16, int MT, int S, bool STASH, bool LAST>
+// SPLIT = false: single f16 product W_hi.h_hi (the lo halves of the weight images and of the activations are ignored).
+template <int KS16, int MT, int S, bool STASH, bool LAST, bool SPLIT>
 __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk, const h16x8 (&Bhi)[KS16],
                                                  const h16x8 (&Blo)[KS16], float inv_scale,
                                                  h16x8 (&Ohi)[2 * MT], h16x8 (&Olo)[2 * MT],
@@ -64,12 +77,14 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
 #pragma unroll
         for (int ks = 0; ks < KS16; ++ks) {
             const h16x8 whi = *reinterpret_cast<const h16x8*>(arow + 16 * ks);
-            const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
 #if LFGC_ABLATE & 4
-            acc[ks & 15] += (float)whi[0] * (float)Bhi[ks][0] + (float)wlo[1] * (float)Blo[ks][1];
+            acc[ks & 15] += (float)whi[0] * (float)Bhi[ks][0];
 #else
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, Bhi[ks], acc, 0, 0, 0);      // small terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Blo[ks], acc, 0, 0, 0);
+            if (SPLIT) {
+                const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, Bhi[ks], acc, 0, 0, 0);      // small terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Blo[ks], acc, 0, 0, 0);
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Bhi[ks], acc, 0, 0, 0);
 #endif
         }
@@ -104,14 +119,19 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
 #pragma unroll
             for (int t = 0; t < 8; ++t) { Ohi[2 * m][t] = (_Float16)hv[t]; Olo[2 * m][t] = (_Float16)0; Ohi[2 * m + 1][t] = (_Float16)hv[8 + t]; Olo[2 * m + 1][t] = (_Float16)0; }
 #else
-            lfgc_split8(hv, Ohi[2 * m], Olo[2 * m]);
-            lfgc_split8(hv + 8, Ohi[2 * m + 1], Olo[2 * m + 1]);
+            if (SPLIT) {
+                lfgc_split8(hv, Ohi[2 * m], Olo[2 * m]);
+                lfgc_split8(hv + 8, Ohi[2 * m + 1], Olo[2 * m + 1]);
+            } else {
+                lfgc_cvt8(hv, Ohi[2 * m]);
+                lfgc_cvt8(hv + 8, Ohi[2 * m + 1]);
+            }
 #endif
         }
     }
 }
 
-template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
+template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwdArgs a) {
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
@@ -217,35 +237,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
         {   // layer 0
             h16x8 X0hi[KS16_0], X0lo[KS16_0];
 #pragma unroll
-            for (int s = 0; s < KS16_0; ++s) lfgc_split8(X + 8 * s, X0hi[s], X0lo[s]);
+            for (int s = 0; s < KS16_0; ++s) {
+                if (SPLIT) lfgc_split8(X + 8 * s, X0hi[s], X0lo[s]);
+                else lfgc_cvt8(X + 8 * s, X0hi[s]);
+            }
             const float* blk = acquire(0);
             if (L == 1)
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true>(blk, X0hi, X0lo, s_scale[8], Ahi, Alo, s_final, ydot, stash_tile, j, hh, lane);
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT>(blk, X0hi, X0lo, s_scale[8], Ahi, Alo, s_final, ydot, stash_tile, j, hh, lane);
             else
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false>(blk, X0hi, X0lo, s_scale[8], Ahi, Alo, s_final, ydot, stash_tile, j, hh, lane);
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false, SPLIT>(blk, X0hi, X0lo, s_scale[8], Ahi, Alo, s_final, ydot, stash_tile, j, hh, lane);
         }
         // hidden layers 1 .. L-2 in ping-pong pairs, then the last one with the head folded in
         {
             int l = 1;
             for (; l + 2 < L; l += 2) {
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
                                                               STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
                 blk = acquire(l + 1);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false>(blk, Bhi, Blo, s_scale[9 + l], Ahi, Alo, s_final, ydot,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT>(blk, Bhi, Blo, s_scale[9 + l], Ahi, Alo, s_final, ydot,
                                                               STASH ? stash_tile + (long long)(l + 1) * (64 * 16 * MT) : nullptr, j, hh, lane);
             }
             if (l + 1 < L) {       // one more non-final layer: A -> B, final consumes B
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
                                                               STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
                 ++l;
                 blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true>(blk, Bhi, Blo, s_scale[8 + l], Ahi, Alo, s_final, ydot,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT>(blk, Bhi, Blo, s_scale[8 + l], Ahi, Alo, s_final, ydot,
                                                              STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
             } else if (l < L) {    // final layer consumes A
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
                                                              STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
             }
         }
@@ -257,9 +280,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     }
 }
 
-template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
-static int lfgc_launch_fwd16_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
-    auto kern = lfgc_fwd16_kernel<CH, MT, NF, WAVES, STREAM, STASH>;
+template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT>
+static int lfgc_launch_fwd16_cfg(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
+    auto kern = lfgc_fwd16_kernel<CH, MT, NF, WAVES, STREAM, STASH, SPLIT>;
     static int lds_limit_set = 0;          // per instantiation; raised once (also keeps launches graph-capturable)
     if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -270,6 +293,12 @@ static int lfgc_launch_fwd16_one(const LfgcFwdArgs& a, int lds_bytes, int grid, 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
+}
+
+template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
+static int lfgc_launch_fwd16_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
+    return a.single ? lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, STASH, false>(a, lds_bytes, grid, stream)
+                    : lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, STASH, true>(a, lds_bytes, grid, stream);
 }
 
 template <int CH, int MT, int NF>

@@ -229,3 +229,20 @@ def test_fused_gt_mse_loss_matches_torch(dev):
     assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
     (3.0 * loss).backward()
     assert rel_err(pred.grad.cpu().numpy(), 3.0 * ref_grad.cpu().numpy()) <= 1e-6
+
+
+def test_reduced_precision_f16_backward(dev):
+    """LFGC_PRECISION_F16 backward: data-gradient chain with single f16 products (per-tile power-of-two scaling keeps the
+    gradients inside the f16 range), weight gradients exact fp32.  Bound: 2e-2 of each tensor's largest entry."""
+    g = np.load(os.path.join(GOLD, 'fwd_c6g17h32l4.npz'))
+    m = build_from_golden(g, dev).train()
+    m.precision = 'f16'
+    pos = torch.from_numpy(g['pos']).to(dev).requires_grad_(True)
+    y = m(pos)
+    loss = torch.nn.functional.mse_loss(y.squeeze(-1), torch.from_numpy(g['target']).to(dev))
+    assert abs(loss.item() - float(g['loss'])) <= 1e-2 * abs(float(g['loss']))
+    loss.backward()
+    ref = {k[5:]: g[k] for k in g.files if k.startswith('grad.')}
+    worst = _grads_vs(m, ref, 2e-2, 'f16')
+    assert worst > 1e-5                       # not accidentally the full-precision path
+    assert rel_err(pos.grad.cpu().numpy(), g['grad_pos']) <= 2e-2

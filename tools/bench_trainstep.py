@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--no-input-grad', action='store_true')
     ap.add_argument('--foreach-adam', action='store_true', help="torch's default (foreach) Adam instead of fused=True")
     ap.add_argument('--graph', action='store_true', help='capture one train step in a HIP graph and replay it')
+    ap.add_argument('--precision', default='f16x2', choices=['f16x2', 'fp32', 'f16'])
     ap.add_argument('--torch-loss', action='store_true', help='GT gather + torch MSELoss instead of the fused GT+MSE kernel')
     ap.add_argument('--drop-type', default='', choices=['', 'smallify', 'masked_straight_through', 'variational'],
                     help='pruning layers on the coefficients + their loss (the reference CLI default is smallify)')
@@ -35,6 +36,7 @@ def main():
     dev = torch.device('cuda:0')
     w = bench.WORKLOADS['headline']
     model = bench.build_model(w, seed=2003, device=dev).train()
+    model.precision = args.precision
     drop_loss = None
     if args.drop_type:
         import torch.nn as nn
