@@ -1,10 +1,12 @@
 """Sparse variational dropout on the wavelet coefficients: counterpart of model/Variational_Dropout_Layer.py
-(likelihood helpers :11-33, VariationalDropoutLoss :36-71, VariationalDropout :74-159, Variance_Model :162-175).
+(likelihood helpers :11-33, VariationalDropoutLoss :36-71, VariationalDropout :74-159, Variance_Model :162-175); same
+public names, constructor arguments, parameters (``log_thetas``, ``log_var``) and return values.
 
-The noisy weight ``w = exp(log_theta) + exp(log_var / 2) * xi`` is a tensor of the layer's size (1/C of the
-coefficients); it is handed to the fused HIP decode as the layer's factor, the kernels return ``d_w`` and autograd
-carries it to ``log_thetas`` / ``log_var``.  All D_KL terms and the coefficient L2 term of the loss are evaluated in one
-reduction launch.
+MI355X-first: the layer does not touch the coefficients itself.  Its noisy weight
+``w = exp(log_theta) + exp(log_var / 2) * xi`` has the layer's size (1/C of the coefficient tensor); ``drop_factor()``
+hands it to the fused HIP decode, whose kernels apply it while staging coefficients and return ``d_w`` (sum over the
+channels), and autograd carries that to ``log_thetas`` / ``log_var`` through the few small ops below.  Every D_KL term and
+the coefficient L2 term of the loss come out of ONE reduction launch (``ops.penalty_sums``).
 """
 from __future__ import annotations
 
@@ -18,32 +20,37 @@ import torch.nn.functional as F
 from .. import _lib, ops
 from .Dropout_Layer import DropFactor, DropoutLayer
 
+_LOG_2PI = math.log(2 * np.pi)
+
+
+# ---- Gaussian likelihood of the prediction (reference :11-33) ---------------------------------------------------
 
 def inference_variational_model(mu, sigma):
+    """One sample of N(mu, sigma) per element."""
     return torch.normal(mu, sigma)
 
 
+def _gaussian_log_density(neg_sq_err, inv_two_var, log_sigma):
+    return inv_two_var * neg_sq_err + (-(_LOG_2PI + (2 * log_sigma)) / 2)
+
+
 def calculate_Log_Likelihood(loss_criterion, predicted_volume, ground_truth_volume, log_sigma):
-    """Gaussian log-likelihood with one scalar log-sigma (reference :16-23)."""
-    x_mu_loss = loss_criterion(predicted_volume, ground_truth_volume)
-    sigma = math.exp(log_sigma)
-    a = 1 / (2 * (sigma ** 2))
-    b = - (math.log(2 * math.pi) + (2 * log_sigma)) / 2
-    return a * (-x_mu_loss) + b, x_mu_loss
+    """Scalar ``log_sigma`` (a Python float); returns (log-likelihood built on the criterion's value, that value)."""
+    fit = loss_criterion(predicted_volume, ground_truth_volume)
+    variance = math.exp(log_sigma) ** 2
+    return _gaussian_log_density(-fit, 1 / (2 * variance), log_sigma), fit
 
 
 def calculate_Log_Likelihood_variance(predicted_volume, ground_truth_volume, variance):
-    """Per-sample Gaussian log-likelihood, ``variance`` = log-sigma per sample (reference :26-33)."""
-    x_mu_loss = (ground_truth_volume - predicted_volume) ** 2
+    """Per-sample ``variance`` = log sigma (a tensor); returns (per-sample log-likelihood, per-sample squared error)."""
+    sq_err = (ground_truth_volume - predicted_volume) ** 2
     sigma = torch.exp(variance)
-    a = 1 / (2 * (sigma ** 2))
-    b = - (math.log(2 * np.pi) + (2 * variance)) / 2
-    return a * (-x_mu_loss) + b, x_mu_loss
+    return _gaussian_log_density(-sq_err, 1 / (2 * (sigma ** 2)), variance), sq_err
 
 
 class VariationalDropoutLoss(nn.Module):
-    """-(log-likelihood - weight_dkl * D_KL - weight_weights * |coefficients|^2), each scaled to the whole volume;
-    ``weight_dkl`` is annealed upwards on every call until ``weight_dkl_max`` (reference :55-71)."""
+    """``-(LL - weight_dkl * D_KL - weight_weights * |coefficients|^2)``, every term scaled from the batch to the whole
+    volume; ``weight_dkl`` anneals upwards by ``(1 + multiplier)`` per call until it passes ``weight_dkl_max``."""
 
     def __init__(self, size_volume: float, batch_size: float, weight_dkl: float = 1., weight_weights: float = 1.,
                  weight_dkl_max=30.0):
@@ -53,36 +60,32 @@ class VariationalDropoutLoss(nn.Module):
         self.weight_dkl_max = weight_dkl_max
         self.weight_weights = float(weight_weights)
 
-    def forward(self, model: nn.Module, predicted_volume, ground_truth_volume, log_sigma, weight_dkl_multiplier):
+    def _penalties(self, model):
+        """(sum of the layers' D_KL, sum of squared coefficients) -- one launch for all of them."""
         from .Feature_Grid_Model import Feature_Grid_Model
-        kinds, tensors, n_dkl = [], [], 0
-        for m in model.modules():
-            if isinstance(m, VariationalDropout):
-                kinds.append(_lib.PENALTY_DKL)
-                tensors += [m.log_thetas, m.log_var]
-                n_dkl += 1
-        for m in model.modules():
-            if isinstance(m, Feature_Grid_Model):
-                kinds += [_lib.PENALTY_L2] * len(m.feature_grid)
-                tensors += list(m.feature_grid)
-        sums = ops.penalty_sums(kinds, tensors) if kinds else None
-        dkl = sums[:n_dkl].sum() if n_dkl else 0
-        weights = sums[n_dkl:].sum() if len(kinds) > n_dkl else 0
+        layers = [m for m in model.modules() if isinstance(m, VariationalDropout)]
+        grids = [g for m in model.modules() if isinstance(m, Feature_Grid_Model) for g in m.feature_grid]
+        if not layers and not grids:
+            return 0, 0
+        kinds = [_lib.PENALTY_DKL] * len(layers) + [_lib.PENALTY_L2] * len(grids)
+        tensors = [t for l in layers for t in (l.log_thetas, l.log_var)] + grids
+        sums = ops.penalty_sums(kinds, tensors)
+        return (sums[:len(layers)].sum() if layers else 0), (sums[len(layers):].sum() if grids else 0)
 
+    def forward(self, model: nn.Module, predicted_volume, ground_truth_volume, log_sigma, weight_dkl_multiplier):
+        dkl, sq_weights = self._penalties(model)
         if self.weight_dkl < self.weight_dkl_max:
             self.weight_dkl = self.weight_dkl * (1.0 + weight_dkl_multiplier)
-
-        Log_Likelyhood, mse = calculate_Log_Likelihood_variance(predicted_volume, ground_truth_volume, log_sigma)
-        mse = mse.sum() * (1 / predicted_volume.shape[0])
-        Log_Likelyhood = Log_Likelyhood.sum() * self.batch_scale
-        Dkl_sum = self.weight_dkl * dkl * self.batch_scale
-        weight_sum = self.weight_weights * weights * self.batch_scale
-        loss = -(Log_Likelyhood - Dkl_sum - weight_sum)
-        return loss, Log_Likelyhood, mse, Dkl_sum, weight_sum
+        per_sample_ll, sq_err = calculate_Log_Likelihood_variance(predicted_volume, ground_truth_volume, log_sigma)
+        mse = sq_err.sum() * (1 / predicted_volume.shape[0])
+        log_likelihood = per_sample_ll.sum() * self.batch_scale
+        dkl_term = self.weight_dkl * dkl * self.batch_scale
+        weight_term = self.weight_weights * sq_weights * self.batch_scale
+        return -(log_likelihood - dkl_term - weight_term), log_likelihood, mse, dkl_term, weight_term
 
 
 class VariationalDropout(DropoutLayer):
-    # constants of the D_KL approximation of Molchanov et al. (reference :75-78)
+    # D_KL approximation constants of Molchanov et al. 2017 (reference :75-78); the penalty kernel uses the same values
     k1 = 0.63576
     k2 = 1.87320
     k3 = 1.48695
@@ -90,67 +93,68 @@ class VariationalDropout(DropoutLayer):
 
     def __init__(self, size=(1, 1, 1), init_dropout=0.5, threshold=0.9):
         super().__init__(size, init_dropout, threshold)
+        log_alpha0 = math.log(init_dropout / (1 - init_dropout))
         self.log_thetas = nn.Parameter(torch.zeros(size), requires_grad=True)
-        log_alphas = math.log(init_dropout / (1 - init_dropout))
-        self.log_var = nn.Parameter(torch.empty(size).fill_(log_alphas), requires_grad=True)   # log sigma^2
+        self.log_var = nn.Parameter(torch.full(size, log_alpha0), requires_grad=True)      # log sigma^2 = log(theta^2 alpha)
         self.d_mask = None
 
+    # ---- derived quantities ------------------------------------------------------------------------------------
     @property
     def alphas(self):
         return torch.exp(self.log_var - 2.0 * self.log_thetas)
 
     @property
-    def dropout_rates(self):
-        return self.alphas / (1.0 + self.alphas)
-
-    @property
     def sigma(self):
         return torch.exp(self.log_var / 2.0)
 
+    @property
+    def dropout_rates(self):
+        a = self.alphas
+        return a / (1.0 + a)
+
+    # ---- the layer's factor for the fused decode ---------------------------------------------------------------
     def _draw(self):
+        """xi ~ N(0, 1) of the layer's size (torch's generator; the parity tests substitute recorded draws)."""
         return torch.randn_like(self.log_thetas)
 
     def drop_factor(self):
-        # noise is injected in train AND eval mode, as in the reference
+        # as in the reference the noise is injected in train AND eval mode (SURVEY App. B4); after pruning only the mask
         if self.d_mask is not None:
             return DropFactor(self.d_mask.to(self.log_thetas.device, torch.float32))
-        thetas = torch.exp(self.log_thetas)
-        xi = self._draw()
-        return DropFactor(thetas + self.sigma * xi)
+        return DropFactor(torch.exp(self.log_thetas) + self.sigma * self._draw())
 
+    # ---- diagnostics / loss terms -------------------------------------------------------------------------------
     def calculate_Dkl(self):
         return ops.penalty_sums([_lib.PENALTY_DKL], [self.log_thetas, self.log_var])[0]
 
     def calculate_Dropout_Entropy(self):
-        drop_rate = self.dropout_rates
-        h = drop_rate * torch.log(drop_rate) + (1.0 - drop_rate) * torch.log(1 - drop_rate)
-        return torch.sum(h)
+        p = self.dropout_rates
+        return torch.sum(p * torch.log(p) + (1.0 - p) * torch.log(1 - p))
 
     def get_valid_fraction(self):
         rates = self.dropout_rates
-        not_dropped = torch.mean((rates < self.threshold).to(torch.float)).item()
-        return not_dropped, rates
+        return torch.mean((rates < self.threshold).to(torch.float)).item(), rates
 
+    # ---- pruning --------------------------------------------------------------------------------------------------
     def calculate_pruning_mask(self, device):
         with torch.no_grad():
-            prune_mask = torch.where(self.dropout_rates < self.threshold, 1.0, 0.0)
-            if prune_mask.numel() - torch.count_nonzero(prune_mask) == 0:
-                prune_mask.data[0] = 1.0
-            self.d_mask = prune_mask.to(device)
-            return prune_mask.to(device)
+            keep = torch.where(self.dropout_rates < self.threshold, 1.0, 0.0)
+            if keep.numel() - torch.count_nonzero(keep) == 0:
+                keep.data[0] = 1.0                     # reference quirk (:144-145), kept
+            self.d_mask = keep.to(device)
+            return keep.to(device)
 
     def multiply_values_with_dropout(self, input, device):
         with torch.no_grad():
-            mask = self.calculate_pruning_mask(device) * torch.exp(self.log_thetas)
-            return input * mask
+            return input * (self.calculate_pruning_mask(device) * torch.exp(self.log_thetas))
 
     def size_layer(self):
         return self.log_thetas.numel()
 
 
 class Variance_Model(nn.Module):
-    """Small ReLU MLP predicting a per-sample log-sigma ('dynamic' variational mode, reference :162-175).  Plain
-    torch: it is not part of the feature-grid path."""
+    """Small ReLU MLP predicting a per-sample log-sigma ('dynamic' variational mode, reference :162-175).  Plain torch:
+    it is not part of the feature-grid path."""
 
     def __init__(self, input_ch=3, output_ch=1, n_layers=4, size_layers=32):
         super().__init__()
