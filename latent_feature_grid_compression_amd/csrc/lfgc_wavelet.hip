@@ -21,7 +21,7 @@ struct IdwtArgs {
     const float* filt;  // (8,4,4,4)
     float* out;         // (C, t0,t1,t2)
     int C, d0, d1, d2, t0, t1, t2, o0, o1, o2;   // o = crop offset floor((2d+2-t)/2)
-    int len;            // plane offsets per staged z-plane (multiple of 256)
+    int len;            // plane offsets per staged z-plane
     float taps[8];      // SEP build: the 1-D bank the filter is the outer product of: [low | high][tap]
     // DROP build only: the pruning layers' per-coefficient factors, shared by all channels
     const float* mul_l; // (d0,d1,d2) or NULL
@@ -46,7 +46,7 @@ constexpr int kTileCells = 128;      // cells of the flattened (y,x) plane per z
 // cell + pad]; element k is plane offset chunk0 + k, chunk0 = (first cell row - 1) * d2 - 1.  The 48-byte records make
 // both the two ds_write_b128 of the staging and the two ds_read_b128 per neighbour cell conflict-free (stride 4 * 3
 // dwords).  Offsets outside the plane (and z-planes outside the level) are staged as zeros, so only the x range of a
-// neighbour needs a select.  `len` is a multiple of 256: one record per thread per staging pass.
+// neighbour needs a select.
 constexpr int kRec = 12;
 
 template <bool DROP, bool SEP>
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
     const long long dvol = (long long)plane_cells * a.d0;
     const float* src = a.src + (long long)c * nplane * a.n0;              // per-channel offsets fit 32 bits (host check)
 #pragma unroll 2
-    for (int kk = threadIdx.x; kk < len; kk += 256) {       // len is a multiple of 256
+    for (int kk = threadIdx.x; kk < len; kk += 256) {
         const int off = chunk0 + kk;
         const bool in_plane = off >= 0 && off < nplane;
         float r[6];
@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
                 float x0 = 0.0f, x1 = 0.0f;
 #pragma unroll
                 for (int tx = 0; tx < 4; ++tx) {
-                    const float val = xok[tx] ? row[tx] : 0.0f;
+                    const float raw = row[tx];                  // always in the chunk: load first, then select (a ternary
+                    const float val = xok[tx] ? raw : 0.0f;     // around the load compiles to an exec-masked branch per tap)
                     x0 = __builtin_fmaf(val, a.taps[tx], x0);
                     x1 = __builtin_fmaf(val, a.taps[4 + tx], x1);
                 }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
         for (int ty = 0; ty < 4; ++ty) {
             const float* row = pl + ty * a.n2;
 #pragma unroll
-            for (int tx = 0; tx < 4; ++tx) v[ty * 4 + tx] = xok[tx] ? row[tx] : 0.0f;
+            for (int tx = 0; tx < 4; ++tx) { const float raw = row[tx]; v[ty * 4 + tx] = xok[tx] ? raw : 0.0f; }
         }
 #pragma unroll
         for (int tyx = 0; tyx < 16; ++tyx) {
@@ -414,7 +415,7 @@ int launch_idwt(IdwtArgs a, bool drop, const float* taps, hipStream_t stream) {
     a.o0 = (2 * a.d0 + 2 - a.t0) / 2; a.o1 = (2 * a.d1 + 2 - a.t1) / 2; a.o2 = (2 * a.d2 + 2 - a.t2) / 2;
     const int n0 = a.d0 + 1, n1 = a.d1 + 1, n2 = a.d2 + 1;
     const int span = (kTileCells + n2 - 2) / n2;            // rows a run of 128 cells can straddle beyond its first
-    a.len = ((span + 2) * a.d2 + 2 + 255) / 256 * 256;      // chunk stride: multiple of the workgroup size
+    a.len = (span + 2) * a.d2 + 2;
     const long long blocks = (long long)a.C * ((n0 + 1) / 2) * (((long long)n1 * n2 + kTileCells - 1) / kTileCells);
     const int lds = (512 + 3 * a.len * kRec) * 4;
     if ((long long)a.d0 * a.d1 * a.d2 > 0x7fffffffLL / 8 || (long long)a.t0 * a.t1 * a.t2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
@@ -428,7 +429,7 @@ int launch_idwt(IdwtArgs a, bool drop, const float* taps, hipStream_t stream) {
 int launch_analysis(AnalysisArgs a, bool drop, const float* taps, hipStream_t stream) {
     if (taps) for (int i = 0; i < 8; ++i) a.taps[i] = taps[i];
     const int span = (kTileCells + a.d2 - 2) / a.d2;
-    a.len = ((2 * span + 3) * a.n2 + 2 * a.d2 + 2 + 255) / 256 * 256;
+    a.len = (2 * span + 3) * a.n2 + 2 * a.d2 + 2;
     const long long blocks = (long long)a.C * ((a.d0 + 1) / 2) * (((long long)a.d1 * a.d2 + kTileCells - 1) / kTileCells);
     const int lds = (512 + 6 * a.len) * 4;
     if ((long long)a.n0 * a.n1 * a.n2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
