@@ -108,11 +108,17 @@ int lfgc_idwt_level_drop_f32(const float* lll, const float* hf, const float* mul
 
 /* Adjoint of lfgc_idwt_level_drop_f32: d_lll / d_hf are OVERWRITTEN with the gradients of the UN-multiplied inputs;
  * the factor gradients are ADDED (float atomics over the channels) into d_mul_lll (d0,d1,d2) / d_mul_hf (7,d0,d1,d2),
- * which the caller zero-fills beforehand (NULL = not wanted; wanting them needs lll / hf). */
+ * which the caller zero-fills beforehand (NULL = not wanted; wanting them needs lll / hf).
+ * penalty_grads: NULL, or a HOST array of 4 device pointers to single floats (each may be NULL) = the upstream gradients
+ * of penalty terms whose own gradients are folded into this pass instead of costing a pass of their own:
+ *   [0] d(loss)/d(sum lll^2)   -> d_lll += 2 g lll        (only where lll is a parameter: the coarsest level)
+ *   [1] d(loss)/d(sum hf^2)    -> d_hf  += 2 g hf         (ΣG² term of SmallifyLoss / VariationalDropoutLoss)
+ *   [2] d(loss)/d(sum |mul_lll|), [3] d(loss)/d(sum |mul_hf|) -> d_mul += g sign(mul), for a factor that is itself the
+ *       penalised parameter (SmallifyDropout.betas, model/Smallify_Dropout.py:63-64). */
 int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* taps, const float* lll, const float* hf,
                                  const float* mul_lll, const float* mul_hf, float* d_lll, float* d_hf,
-                                 float* d_mul_lll, float* d_mul_hf, int C, int d0, int d1, int d2,
-                                 int t0, int t1, int t2, lfgc_stream_t stream);
+                                 float* d_mul_lll, float* d_mul_hf, const float* const* penalty_grads,
+                                 int C, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
 
 /* One drop layer on one tensor outside the decode (the layers' own forward(x)): x, out (C, n), mul (n). */
 int lfgc_drop_apply_f32(const float* x, const float* mul, float threshold, float* out, int C, int64_t n,

@@ -46,7 +46,7 @@ SIGNATURES = {
     'lfgc_dwt_level_f32': (c_int, [c_void_p, c_void_p, _TAPS, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'lfgc_idwt_level_drop_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, _TAPS, c_void_p] +
                                  [c_int] * 7 + [c_void_p]),
-    'lfgc_idwt_level_drop_bwd_f32': (c_int, [c_void_p, c_void_p, _TAPS] + [c_void_p] * 8 + [c_int] * 7 + [c_void_p]),
+    'lfgc_idwt_level_drop_bwd_f32': (c_int, [c_void_p, c_void_p, _TAPS] + [c_void_p] * 8 + [_PP] + [c_int] * 7 + [c_void_p]),
     'lfgc_drop_apply_f32': (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64, c_void_p]),
     'lfgc_drop_apply_bwd_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     'lfgc_sign_variance_update_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),

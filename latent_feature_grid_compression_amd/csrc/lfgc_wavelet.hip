@@ -209,7 +209,13 @@ struct AnalysisArgs {
     const float* mul_h;    // (7, d0,d1,d2) or NULL
     float* d_mul_l;        // (d0,d1,d2) or NULL, pre-zeroed
     float* d_mul_h;        // (7, d0,d1,d2) or NULL, pre-zeroed
+    // penalty gradients folded in (device scalars or NULL): upstream gradient of  sum coef^2  of the low / detail tensor
+    // (adds 2 g coef to its gradient) and of  sum |factor|  of a factor that is itself the penalised parameter
+    // (Smallify beta: adds g sign(factor) to the factor gradient, once, by the channel-0 workgroups)
+    const float* g_l2_l; const float* g_l2_h; const float* g_l1_l; const float* g_l1_h;
 };
+
+__device__ __forceinline__ float sign_of(float v) { return (float)((v > 0.0f) - (v < 0.0f)); }
 
 template <bool DROP, bool SEP>
 __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
@@ -323,16 +329,28 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
     if (valid) {
         const long long sp = (long long)iz * plane_cells + fc;
         if (DROP) {
-            if (a.mul_l) {
-                if (a.d_mul_l) atomicAdd(a.d_mul_l + sp, acc[0] * a.lll[(long long)c * dvol + sp]);
-                acc[0] *= a.mul_l[sp];
+            if (a.mul_l || a.g_l2_l) {
+                const float x = (a.d_mul_l || a.g_l2_l) ? a.lll[(long long)c * dvol + sp] : 0.0f;
+                if (a.mul_l) {
+                    const float m = a.mul_l[sp];
+                    if (a.d_mul_l) atomicAdd(a.d_mul_l + sp, acc[0] * x + ((a.g_l1_l && c == 0) ? *a.g_l1_l * sign_of(m) : 0.0f));
+                    acc[0] *= m;
+                }
+                if (a.g_l2_l) acc[0] = __builtin_fmaf(2.0f * *a.g_l2_l, x, acc[0]);
             }
-            if (a.mul_h) {
+            if (a.mul_h || a.g_l2_h) {
+                const float g2 = a.g_l2_h ? 2.0f * *a.g_l2_h : 0.0f;
+                const float g1 = (a.g_l1_h && c == 0) ? *a.g_l1_h : 0.0f;
 #pragma unroll
                 for (int s = 1; s < 8; ++s) {
                     const long long o = (long long)(s - 1) * dvol + sp;
-                    if (a.d_mul_h) atomicAdd(a.d_mul_h + o, acc[s] * a.hf[(long long)c * 7 * dvol + o]);
-                    acc[s] *= a.mul_h[o];
+                    const float x = (a.d_mul_h || a.g_l2_h) ? a.hf[(long long)c * 7 * dvol + o] : 0.0f;
+                    if (a.mul_h) {
+                        const float m = a.mul_h[o];
+                        if (a.d_mul_h) atomicAdd(a.d_mul_h + o, acc[s] * x + g1 * sign_of(m));
+                        acc[s] *= m;
+                    }
+                    acc[s] = __builtin_fmaf(g2, x, acc[s]);
                 }
             }
         }
@@ -485,14 +503,19 @@ extern "C" int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_r
 
 extern "C" int lfgc_idwt_level_drop_bwd_f32(const float* d_out, const float* filter_rev, const float* taps, const float* lll, const float* hf,
                                             const float* mul_lll, const float* mul_hf, float* d_lll, float* d_hf,
-                                            float* d_mul_lll, float* d_mul_hf, int C, int d0, int d1, int d2,
+                                            float* d_mul_lll, float* d_mul_hf, const float* const* penalty_grads,
+                                            int C, int d0, int d1, int d2,
                                             int t0, int t1, int t2, lfgc_stream_t stream) {
     const int rc = check_level(d_out, taps ? (const void*)taps : (const void*)filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
     if (rc != LFGC_OK) return rc;
     if ((d_mul_lll && (!mul_lll || !lll)) || (d_mul_hf && (!mul_hf || !hf))) return LFGC_E_NULL;
+    const float* pg[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (penalty_grads) for (int i = 0; i < 4; ++i) pg[i] = penalty_grads[i];
+    if ((pg[0] && !lll) || (pg[1] && !hf) || (pg[2] && !d_mul_lll) || (pg[3] && !d_mul_hf)) return LFGC_E_NULL;
     AnalysisArgs a = adjoint_args(d_out, filter_rev, d_lll, d_hf, C, d0, d1, d2, t0, t1, t2);
     a.lll = lll; a.hf = hf; a.mul_l = mul_lll; a.mul_h = mul_hf; a.d_mul_l = d_mul_lll; a.d_mul_h = d_mul_hf;
-    return launch_analysis(a, mul_lll || mul_hf, taps, (hipStream_t)stream);
+    a.g_l2_l = pg[0]; a.g_l2_h = pg[1]; a.g_l1_l = pg[2]; a.g_l1_h = pg[3];
+    return launch_analysis(a, mul_lll || mul_hf || pg[0] || pg[1], taps, (hipStream_t)stream);
 }
 
 extern "C" int lfgc_dwt_level_f32(const float* in, const float* filter_fwd, const float* taps, float* out,

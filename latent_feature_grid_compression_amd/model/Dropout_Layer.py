@@ -24,6 +24,8 @@ class DropFactor(NamedTuple):
     with the gradient of x * mul."""
     mul: torch.Tensor
     threshold: Optional[float] = None
+    l1_target: bool = False      # ``mul`` IS the parameter the layer's L1 penalty is taken of (Smallify betas): its penalty
+                                 # gradient can then ride in the decode's adjoint kernels
 
 
 class DropoutLayer(torch.nn.Module):

@@ -65,6 +65,7 @@ class Feature_Grid_Model(nn.Module):
         self.precision = 'f16x2'
         self._grid_cache = None      # (key, channel-last dense grid) while parameters are unchanged (eval)
         self._pack_cache = None      # (key, packed MLP blob)
+        self._penalty_cache = None   # penalty sums taken inside the last differentiable fused decode
         self._desc = None
 
     # ---- host-side keys for the caches: (data_ptr, in-place version) of every tensor involved -----------
@@ -96,7 +97,7 @@ class Feature_Grid_Model(nn.Module):
         """Coefficient tensors with their drop layers resolved (reference :103, :105): this package's layers only
         name their per-coefficient factor -- the multiply happens inside the IDWT kernels --, any other module
         (nn.Identity, a reference DropoutLayer object handed in by the caller) is called as it is."""
-        coeffs, factors, thresholds = [], [], []
+        coeffs, factors, thresholds, l1_flags = [], [], [], []
         DropoutLayer.prepare(self.drop)
         for g, d in zip(self.feature_grid, self.drop):
             f = d.drop_factor() if isinstance(d, DropoutLayer) else None
@@ -105,10 +106,28 @@ class Feature_Grid_Model(nn.Module):
             coeffs.append(g)
             factors.append(None if f is None else f.mul)
             thresholds.append(None if f is None else f.threshold)
-        return coeffs, factors, thresholds
+            l1_flags.append(bool(f is not None and f.l1_target))
+        return coeffs, factors, thresholds, l1_flags
+
+    def _penalty_key(self):
+        """Identity + in-place version of every tensor the cached penalty sums were taken of."""
+        ts = list(self.feature_grid) + [p for d in self.drop for p in d.parameters()]
+        return tuple((id(t), t._version) for t in ts)
+
+    def cached_penalties(self):
+        """(sum of squared coefficients per tensor (n,), {drop-layer index: its L1 term}) from the last differentiable
+        decode, with their gradients riding in that decode's backward kernels -- or None if no decode has run since a
+        parameter last changed (the pruning losses then evaluate the terms with a launch of their own)."""
+        c = self._penalty_cache
+        if c is None or c['key'] != self._penalty_key() or not torch.is_grad_enabled():
+            return None
+        n = c['n']
+        l1 = {i: c['pen'][n + j] for j, i in enumerate(c['l1_idx'])}
+        return c['pen'][:n], l1
 
     def _decode(self, channel_last: bool) -> torch.Tensor:
-        coeffs, factors, thresholds = self._dropped()
+        coeffs, factors, thresholds, l1_flags = self._dropped()
+        self._penalty_cache = None
         fused = any(f is not None for f in factors)
         if fused and len(coeffs) == 1:                     # no wavelet level at all: the layer is all there is
             coeffs = [ops.DropApplyFn.apply(coeffs[0], factors[0], thresholds[0])]
@@ -116,8 +135,16 @@ class Feature_Grid_Model(nn.Module):
         track = torch.is_grad_enabled() and any(t.requires_grad for t in coeffs + [f for f in factors if f is not None])
         if fused:
             if track:
-                return ops.DecodeVolumeDropFn.apply(self.filter.filter_rev, self.shape_array, channel_last, thresholds,
-                                                    len(coeffs), *[c.contiguous() for c in coeffs], *factors)
+                # penalty sums of the coefficients (and of factors that are themselves L1-penalised parameters) come
+                # out of the same node, so that their gradients ride in its adjoint kernels (SmallifyLoss /
+                # VariationalDropoutLoss pick them up through cached_penalties())
+                n = len(coeffs)
+                grid, pen = ops.DecodeVolumePenaltyFn.apply(self.filter.filter_rev, self.shape_array, channel_last,
+                                                            thresholds, n, l1_flags,
+                                                            *[c.contiguous() for c in coeffs], *factors)
+                self._penalty_cache = {'key': self._penalty_key(), 'pen': pen, 'n': n,
+                                       'l1_idx': [i for i in range(n) if l1_flags[i] and factors[i] is not None]}
+                return grid
             return ops.decode_levels_drop([c.detach() for c in coeffs], [None if f is None else f.detach() for f in factors],
                                           thresholds, self.shape_array, self.filter.filter_rev, channel_last)
         if track:

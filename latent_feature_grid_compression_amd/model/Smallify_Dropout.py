@@ -38,26 +38,42 @@ class SmallifyLoss(nn.Module):
 
     def forward(self, model: nn.Module) -> torch.Tensor:
         from .Feature_Grid_Model import Feature_Grid_Model
-        l1, l2 = [], []
+        l1, l2 = [], []                    # tensors still to be reduced here
+        pre_l1, pre_l2 = [], []            # terms the model's last decode already holds (their gradients ride in its backward)
+        covered = set()
+        for m in model.modules():
+            if isinstance(m, Feature_Grid_Model):
+                cached = m.cached_penalties()
+                if cached is not None:
+                    pre_l2.append(cached[0])
+                    for i, term in cached[1].items():
+                        if _l1_parameter(m.drop[i]) is not None:
+                            pre_l1.append(term)
+                            covered.add(id(m.drop[i]))
+                else:
+                    l2.extend(m.feature_grid)
         for m in model.modules():
             p = _l1_parameter(m)
-            if p is not None:
+            if p is not None and id(m) not in covered:
                 l1.append(p)
-            if isinstance(m, Feature_Grid_Model):
-                l2.extend(m.feature_grid)
-        use_l1 = self.weight_l1 > 0. and l1
-        use_l2 = self.weight_l2 > 0. and l2
+        use_l1, use_l2 = self.weight_l1 > 0., self.weight_l2 > 0.
         tensors = (l1 if use_l1 else []) + (l2 if use_l2 else [])
-        if not tensors:
-            return 0.
-        kinds = [_lib.PENALTY_L1] * (len(l1) if use_l1 else 0) + [_lib.PENALTY_L2] * (len(l2) if use_l2 else 0)
-        sums = ops.penalty_sums(kinds, tensors)
         n1 = len(l1) if use_l1 else 0
+        sums = None
+        if tensors:
+            kinds = [_lib.PENALTY_L1] * n1 + [_lib.PENALTY_L2] * (len(tensors) - n1)
+            sums = ops.penalty_sums(kinds, tensors)
         loss = 0.
-        if use_l1:
-            loss = loss + self.weight_l1 * sums[:n1].sum()
-        if use_l2:
-            loss = loss + self.weight_l2 * sums[n1:].sum()
+        if use_l1 and (n1 or pre_l1):
+            total = sums[:n1].sum() if n1 else 0.
+            for t in pre_l1:
+                total = total + t
+            loss = loss + self.weight_l1 * total
+        if use_l2 and (len(tensors) > n1 or pre_l2):
+            total = sums[n1:].sum() if len(tensors) > n1 else 0.
+            for t in pre_l2:
+                total = total + t.sum()
+            loss = loss + self.weight_l2 * total
         return loss
 
 
@@ -96,7 +112,7 @@ class SmallifyDropout(DropoutLayer):
             self._tracker_stepped = False                 # done for this forward by _prepare_group
         else:
             self.tracker.sign_variance_pruning_onlyVar(self.betas)
-        return DropFactor(self.betas)
+        return DropFactor(self.betas, None, True)
 
     def l1_loss(self):
         return ops.penalty_sums([_lib.PENALTY_L1], [self.betas])[0]

@@ -64,13 +64,20 @@ class VariationalDropoutLoss(nn.Module):
         """(sum of the layers' D_KL, sum of squared coefficients) -- one launch for all of them."""
         from .Feature_Grid_Model import Feature_Grid_Model
         layers = [m for m in model.modules() if isinstance(m, VariationalDropout)]
-        grids = [g for m in model.modules() if isinstance(m, Feature_Grid_Model) for g in m.feature_grid]
-        if not layers and not grids:
-            return 0, 0
+        grids, pre_sq = [], 0
+        for m in model.modules():
+            if isinstance(m, Feature_Grid_Model):
+                cached = m.cached_penalties()          # sums taken inside the last decode: gradients ride in its backward
+                if cached is not None:
+                    pre_sq = pre_sq + cached[0].sum()
+                else:
+                    grids += list(m.feature_grid)
         kinds = [_lib.PENALTY_DKL] * len(layers) + [_lib.PENALTY_L2] * len(grids)
+        if not kinds:
+            return 0, pre_sq
         tensors = [t for l in layers for t in (l.log_thetas, l.log_var)] + grids
         sums = ops.penalty_sums(kinds, tensors)
-        return (sums[:len(layers)].sum() if layers else 0), (sums[len(layers):].sum() if grids else 0)
+        return (sums[:len(layers)].sum() if layers else 0), (sums[len(layers):].sum() + pre_sq if grids else pre_sq)
 
     def forward(self, model: nn.Module, predicted_volume, ground_truth_volume, log_sigma, weight_dkl_multiplier):
         dkl, sq_weights = self._penalties(model)

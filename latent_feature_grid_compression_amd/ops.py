@@ -241,9 +241,11 @@ def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> 
     return out
 
 
-def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml, want_dmh, d):
+def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml, want_dmh, d, penalty_ptrs=None):
     """Adjoint of idwt_level_drop -> (d_lll, d_hf, d_mul_l or None, d_mul_h or None).  want_dml / want_dmh: False, True
-    (a zero tensor is allocated) or a ZERO-FILLED tensor of the factor's shape to accumulate into."""
+    (a zero tensor is allocated) or a ZERO-FILLED tensor of the factor's shape to accumulate into.  penalty_ptrs: None or
+    4 device addresses (0 = none) of the upstream gradients of [sum lll^2, sum hf^2, sum |mul_l|, sum |mul_h|] whose own
+    gradients the kernel folds in (include/lfgc.h)."""
     _require_hip(d_out, filter_rev)
     taps = filter_taps(filter_rev)
     d_out, filter_rev = _f32c(d_out), _f32c(filter_rev)
@@ -257,9 +259,10 @@ def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml, want
     d_mh = want_dmh if torch.is_tensor(want_dmh) else (
         torch.zeros((7, d[0], d[1], d[2]), dtype=torch.float32, device=dev) if want_dmh else None)
     ptr = lambda t: t.data_ptr() if t is not None else None
+    pen, _keep = (None, None) if penalty_ptrs is None else _lib.ptr_array([int(v) for v in penalty_ptrs])
     check(_lib.load().lfgc_idwt_level_drop_bwd_f32(
         d_out.data_ptr(), filter_rev.data_ptr(), taps, ptr(lll), ptr(hf), ptr(mul_l), ptr(mul_h), d_lll.data_ptr(),
-        d_hf.data_ptr(), ptr(d_ml), ptr(d_mh), C, d[0], d[1], d[2], t0, t1, t2, _stream(d_out)),
+        d_hf.data_ptr(), ptr(d_ml), ptr(d_mh), pen, C, d[0], d[1], d[2], t0, t1, t2, _stream(d_out)),
         'lfgc_idwt_level_drop_bwd_f32')
     return d_lll, d_hf, d_ml, d_mh
 
@@ -326,6 +329,7 @@ class DecodeVolumeDropFn(torch.autograd.Function):
         ctx.dims = [tuple(c.shape) for c in coeffs]
         ctx.want = [f is not None and f.requires_grad for f in factors]
         ctx.has = [f is not None for f in factors]
+        ctx.l1_flags = [False] * n
         det = [c.detach() for c in coeffs]
         fdet = [f.detach() if f is not None else None for f in factors]
         ctx.save_for_backward(*det, *[f for f in fdet if f is not None])
@@ -334,33 +338,89 @@ class DecodeVolumeDropFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_out):
-        n = ctx.n
-        saved = list(ctx.saved_tensors)
-        coeffs = saved[:n]
-        it = iter(saved[n:])
-        factors = [next(it) if h else None for h in ctx.has]
-        C = ctx.dims[0][0]
-        g = to_channel_first(d_out, C) if ctx.channel_last else d_out
-        d_coef, d_fac = [None] * n, [None] * n
-        # the factor gradients are accumulated with atomics: one zero fill for all of them
-        sizes = [int(np.prod(ctx.dims[i][1:])) if ctx.want[i] else 0 for i in range(n)]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=g.device) if sum(sizes) else None
-        zeroed, at = [False] * n, 0
-        for i in range(n):
-            if sizes[i]:
-                zeroed[i] = flat[at:at + sizes[i]].view(ctx.dims[i][1:])
-                at += sizes[i]
-        for lvl in range(n - 1, 0, -1):
-            first = lvl == 1
-            ml = factors[0] if first else None
-            g, d_hf, d_ml, d_mh = idwt_level_drop_bwd(
-                g, ctx.filter_rev, coeffs[0] if first else None, coeffs[lvl], ml, factors[lvl],
-                zeroed[0] if first else False, zeroed[lvl], ctx.dims[lvl][2:])
-            d_coef[lvl], d_fac[lvl] = d_hf, d_mh
-            if first:
-                d_fac[0] = d_ml
-        d_coef[0] = g
+        d_coef, d_fac = _decode_drop_backward(ctx, d_out, None)
         return (None, None, None, None, None) + tuple(d_coef) + tuple(d_fac)
+
+
+def _decode_drop_backward(ctx, d_out, d_pen):
+    """Shared backward of the two decode-with-factors nodes; d_pen fp32 or None = upstream gradients of the penalty sums
+    (layout of DecodeVolumePenaltyFn) folded into the adjoint kernels."""
+    n = ctx.n
+    saved = list(ctx.saved_tensors)
+    coeffs = saved[:n]
+    it = iter(saved[n:])
+    factors = [next(it) if h else None for h in ctx.has]
+    C = ctx.dims[0][0]
+    g = to_channel_first(d_out, C) if ctx.channel_last else d_out
+    d_coef, d_fac = [None] * n, [None] * n
+    # the factor gradients are accumulated with atomics: one zero fill for all of them
+    sizes = [int(np.prod(ctx.dims[i][1:])) if ctx.want[i] else 0 for i in range(n)]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=g.device) if sum(sizes) else None
+    zeroed, at = [False] * n, 0
+    for i in range(n):
+        if sizes[i]:
+            zeroed[i] = flat[at:at + sizes[i]].view(ctx.dims[i][1:])
+            at += sizes[i]
+    if d_pen is not None:
+        d_pen = _f32c(d_pen)
+        base = d_pen.data_ptr()
+        l2 = lambda i: base + 4 * i
+        l1 = lambda i: (base + 4 * (n + ctx.l1_pos[i])) if (ctx.l1_flags[i] and zeroed[i] is not False) else 0
+    for lvl in range(n - 1, 0, -1):
+        first = lvl == 1
+        ml = factors[0] if first else None
+        pens = None
+        if d_pen is not None:
+            pens = [l2(0) if first else 0, l2(lvl), l1(0) if first else 0, l1(lvl)]
+        g, d_hf, d_ml, d_mh = idwt_level_drop_bwd(
+            g, ctx.filter_rev, coeffs[0] if (first and (ctx.has[0] or d_pen is not None)) else None, coeffs[lvl], ml,
+            factors[lvl], zeroed[0] if first else False, zeroed[lvl], ctx.dims[lvl][2:], pens)
+        d_coef[lvl], d_fac[lvl] = d_hf, d_mh
+        if first:
+            d_fac[0] = d_ml
+    d_coef[0] = g
+    return d_coef, d_fac
+
+
+class DecodeVolumePenaltyFn(torch.autograd.Function):
+    """DecodeVolumeDropFn that also returns the penalty sums of its inputs, so that their gradients ride in the adjoint
+    kernels instead of costing passes (and autograd accumulation adds) of their own:
+    apply(filter_rev, shape_array, channel_last, thresholds, n, l1_flags, *coeffs, *factors) -> (grid, pen) with
+    pen fp32 = [sum coeffs[i]^2 for i in range(n)] followed by [sum |factors[i]| for the i with l1_flags[i]] (in order):
+    factors that ARE the penalised parameter, e.g. Smallify betas."""
+
+    @staticmethod
+    def forward(ctx, filter_rev, shape_array, channel_last, thresholds, n, l1_flags, *tensors):
+        coeffs, factors = tensors[:n], tensors[n:]
+        ctx.set_materialize_grads(False)
+        ctx.filter_rev = filter_rev
+        ctx.shape_array = [tuple(int(v) for v in s) for s in shape_array]
+        ctx.channel_last = bool(channel_last)
+        ctx.n = n
+        ctx.l1_flags = [bool(f) and factors[i] is not None for i, f in enumerate(l1_flags)]
+        ctx.dims = [tuple(c.shape) for c in coeffs]
+        ctx.want = [f is not None and f.requires_grad for f in factors]
+        ctx.has = [f is not None for f in factors]
+        det = [c.detach() for c in coeffs]
+        fdet = [f.detach() if f is not None else None for f in factors]
+        ctx.save_for_backward(*det, *[f for f in fdet if f is not None])
+        with torch.no_grad():
+            grid = decode_levels_drop(det, fdet, list(thresholds), ctx.shape_array, filter_rev, ctx.channel_last)
+            l1_idx = [i for i in range(n) if ctx.l1_flags[i]]
+            kinds = [_lib.PENALTY_L2] * n + [_lib.PENALTY_L1] * len(l1_idx)
+            terms, keep = _penalty_terms(kinds, det + [fdet[i] for i in l1_idx])
+            sums = torch.empty(len(kinds) * (1 + _lib.PENALTY_BLOCKS), dtype=torch.float64, device=grid.device)
+            check(_lib.load().lfgc_penalty_sums_f32(terms, len(kinds), sums.data_ptr(), _stream(sums)), 'lfgc_penalty_sums_f32')
+            pen = sums[:len(kinds)].float()
+        ctx.l1_pos = {i: j for j, i in enumerate(l1_idx)}
+        return grid, pen
+
+    @staticmethod
+    def backward(ctx, d_out, d_pen):
+        if d_out is None:
+            raise RuntimeError('the decoded grid took no part in the loss (only its penalties did): unsupported')
+        d_coef, d_fac = _decode_drop_backward(ctx, d_out, d_pen)
+        return (None, None, None, None, None, None) + tuple(d_coef) + tuple(d_fac)
 
 
 def sign_variance_update(betas: torch.Tensor, ema: torch.Tensor, emavar: torch.Tensor, momentum: float) -> None:
