@@ -9,6 +9,7 @@ behind ``torch.autograd.Function``.  There is no CPU path: a CPU tensor raises.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -139,6 +140,13 @@ class Feature_Grid_Model(nn.Module):
                 # out of the same node, so that their gradients ride in its adjoint kernels (SmallifyLoss /
                 # VariationalDropoutLoss pick them up through cached_penalties())
                 n = len(coeffs)
+                if not any(l1_flags) or os.environ.get('LFGC_NO_PENALTY_FOLD'):
+                    # measured (tools/microbench/penalty_fold_ab.py, cfg-3 step replayed from a HIP graph): the node with
+                    # the penalty outputs pays off for Smallify layers (0.66 vs 0.69 ms) but replays 0.08-0.27 ms SLOWER
+                    # with the masked / variational layers although it launches less work -- so it is used only where a
+                    # factor is itself an L1-penalised parameter
+                    return ops.DecodeVolumeDropFn.apply(self.filter.filter_rev, self.shape_array, channel_last, thresholds,
+                                                        n, *[c.contiguous() for c in coeffs], *factors)
                 grid, pen = ops.DecodeVolumePenaltyFn.apply(self.filter.filter_rev, self.shape_array, channel_last,
                                                             thresholds, n, l1_flags,
                                                             *[c.contiguous() for c in coeffs], *factors)
