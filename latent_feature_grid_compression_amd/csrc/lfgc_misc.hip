@@ -182,18 +182,26 @@ struct PackArgs {
 // Per-layer power-of-two scale for the f16-split blocks: 2^S with max|W| * 2^S in [2^13, 2^14), so that the hi
 // halves stay far below the f16 maximum and the lo halves (<= 2^-11 of the hi) stay normal for every weight within
 // 2^-16 of the largest.  One block per hidden layer.
-__global__ __launch_bounds__(256) void pack_scale_kernel(const PackArgs a) {
+__global__ __launch_bounds__(1024) void pack_scale_kernel(const PackArgs a) {
     const LfgcPlan& p = a.plan;
     const int l = blockIdx.x;
     const int n = (l == 0) ? p.H * (p.E + p.C) : p.H * p.H;
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(a.w[l][i]));
+    const float* w = a.w[l];
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;      // 4 loads in flight per pass (it runs in every training forward)
+    for (int i = threadIdx.x; i < n; i += 4096) {
+        m0 = fmaxf(m0, fabsf(w[i]));
+        if (i + 1024 < n) m1 = fmaxf(m1, fabsf(w[i + 1024]));
+        if (i + 2048 < n) m2 = fmaxf(m2, fabsf(w[i + 2048]));
+        if (i + 3072 < n) m3 = fmaxf(m3, fabsf(w[i + 3072]));
+    }
+    float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off));
-    __shared__ float s[4];
+    __shared__ float s[16];
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        m = 0.0f;
+        for (int k = 0; k < 16; ++k) m = fmaxf(m, s[k]);
         int e = 0;
         if (m > 0.0f && m < INFINITY) { (void)frexpf(m, &e); e = 14 - e; }    // m = f * 2^e', f in [0.5,1) -> m * 2^(14-e') in [2^13, 2^14)
         if (e > 60) e = 60;
@@ -420,7 +428,7 @@ extern "C" int lfgc_pack_mlp_f32(const lfgc_mlp_desc* d, const float* const* wei
         a.b[l] = biases[l];
     }
     a.packed = packed;
-    hipLaunchKernelGGL(pack_scale_kernel, dim3(a.plan.L), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(pack_scale_kernel, dim3(a.plan.L), dim3(1024), 0, (hipStream_t)stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     const int g = (a.plan.total_floats + 255) / 256;
     hipLaunchKernelGGL(pack_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, (hipStream_t)stream, a);

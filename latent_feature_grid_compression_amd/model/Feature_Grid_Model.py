@@ -69,10 +69,25 @@ class Feature_Grid_Model(nn.Module):
         self._penalty_cache = None   # penalty sums taken inside the last differentiable fused decode
         self._desc = None
 
-    # ---- host-side keys for the caches: (data_ptr, in-place version) of every tensor involved -----------
+    # ---- caches -------------------------------------------------------------------------------------------
+    # Derived device data (decoded channel-last grid, packed MLP blob) is cached ONLY in eval mode, keyed on
+    # (data_ptr, in-place version) of every source tensor, and dropped on every train()/eval() call.  In training mode
+    # nothing is cached: torch's fused optimizers (Adam(fused=True)) update parameters WITHOUT bumping their version
+    # counters (tools/microbench/adam_version.py), so a version key alone would serve stale weights after a step.
     @staticmethod
     def _key(tensors) -> tuple:
         return tuple((t.data_ptr(), t._version, t.device.index) for t in tensors)
+
+    def invalidate_caches(self) -> None:
+        """Forget every derived buffer.  Called by train()/eval(); call it yourself after changing parameters in eval
+        mode through an op that does not bump tensor versions."""
+        self._grid_cache = None
+        self._pack_cache = None
+        self._penalty_cache = None
+
+    def train(self, mode: bool = True):
+        self.invalidate_caches()
+        return super().train(mode)
 
     def _mlp_params(self):
         layers = list(self.net_layers) + [self.final_layer]
@@ -86,6 +101,8 @@ class Feature_Grid_Model(nn.Module):
 
     def _packed(self) -> torch.Tensor:
         weights, biases = self._mlp_params()
+        if self.training:
+            return ops.pack_mlp(self._descriptor(), weights, biases)
         key = self._key(weights + biases)
         if self._pack_cache is None or self._pack_cache[0] != key:
             self._pack_cache = (key, ops.pack_mlp(self._descriptor(), weights, biases))
@@ -165,7 +182,7 @@ class Feature_Grid_Model(nn.Module):
         cached across calls in no-grad mode while no coefficient changed (the reference re-decodes the
         whole grid for every 32^3 tile, visualization/OutputToVTK.py:41)."""
         track = torch.is_grad_enabled() and any(p.requires_grad for p in self.feature_grid)
-        cacheable = (not track) and self._identity_drop()
+        cacheable = (not track) and (not self.training) and self._identity_drop()
         key = self._key(list(self.feature_grid) + [self.filter.filter_rev]) if cacheable else None
         if cacheable and self._grid_cache is not None and self._grid_cache[0] == key:
             return self._grid_cache[1]

@@ -246,3 +246,35 @@ def test_reduced_precision_f16_backward(dev):
     worst = _grads_vs(m, ref, 2e-2, 'f16')
     assert worst > 1e-5                       # not accidentally the full-precision path
     assert rel_err(pos.grad.cpu().numpy(), g['grad_pos']) <= 2e-2
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_forward_follows_optimizer_updates(dev, fused):
+    """torch's fused Adam updates parameters without bumping their version counters: the forward must still see the new
+    weights (nothing derived from the parameters may be cached in training mode), and an eval() after training must
+    re-decode / re-pack."""
+    g = np.load(os.path.join(GOLD, 'fwd_c4g15h16l3.npz'))
+    m = build_from_golden(g, dev).train()
+    pos = torch.from_numpy(g['pos']).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=0.05, fused=fused)
+    m.eval()
+    with torch.no_grad():
+        y_eval0 = m(pos.view(1, -1, 1, 1, 3)).reshape(-1).clone()
+    m.train()
+    for _ in range(3):
+        opt.zero_grad()
+        m(pos).square().mean().backward()
+        opt.step()
+    with torch.no_grad():
+        y_train = m(pos).reshape(-1)
+    fresh = build_from_golden(g, dev)
+    fresh.load_state_dict(m.state_dict())
+    fresh.train()
+    with torch.no_grad():
+        y_ref = fresh(pos).reshape(-1)
+    assert torch.equal(y_train, y_ref)
+    assert (y_train - y_eval0.clamp(-1, 1)).abs().max() > 1e-3            # the steps really changed the function
+    m.eval()
+    with torch.no_grad():
+        y_eval1 = m(pos.view(1, -1, 1, 1, 3)).reshape(-1)
+    assert torch.equal(y_eval1, y_ref.clamp(-1, 1))
