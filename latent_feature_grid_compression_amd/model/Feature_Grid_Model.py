@@ -136,7 +136,7 @@ class Feature_Grid_Model(nn.Module):
         """(sum of squared coefficients per tensor (n,), {drop-layer index: its L1 term}) from the last differentiable
         decode, with their gradients riding in that decode's backward kernels -- or None if no decode has run since a
         parameter last changed (the pruning losses then evaluate the terms with a launch of their own)."""
-        c = self._penalty_cache
+        c, self._penalty_cache = self._penalty_cache, None      # consumed once: see _decode on why no reference is kept
         if c is None or c['key'] != self._penalty_key() or not torch.is_grad_enabled():
             return None
         n = c['n']
@@ -157,13 +157,12 @@ class Feature_Grid_Model(nn.Module):
                 # out of the same node, so that their gradients ride in its adjoint kernels (SmallifyLoss /
                 # VariationalDropoutLoss pick them up through cached_penalties())
                 n = len(coeffs)
-                if not any(l1_flags) or os.environ.get('LFGC_NO_PENALTY_FOLD'):
-                    # measured (tools/microbench/penalty_fold_ab.py, cfg-3 step replayed from a HIP graph): the node with
-                    # the penalty outputs pays off for Smallify layers (0.66 vs 0.69 ms) but replays 0.08-0.27 ms SLOWER
-                    # with the masked / variational layers although it launches less work -- so it is used only where a
-                    # factor is itself an L1-penalised parameter
+                if os.environ.get('LFGC_NO_PENALTY_FOLD'):       # diagnostics (tools/microbench/penalty_fold_ab.py)
                     return ops.DecodeVolumeDropFn.apply(self.filter.filter_rev, self.shape_array, channel_last, thresholds,
                                                         n, *[c.contiguous() for c in coeffs], *factors)
+                # NOTE the cache below is handed out ONCE (cached_penalties pops it): a reference to `pen` that outlives
+                # the step made the HIP-graph replay of the whole train step 0.25 ms slower (measured; a tensor of the
+                # captured region kept alive past the capture), which had hidden the gain of the fold for two layer types
                 grid, pen = ops.DecodeVolumePenaltyFn.apply(self.filter.filter_rev, self.shape_array, channel_last,
                                                             thresholds, n, l1_flags,
                                                             *[c.contiguous() for c in coeffs], *factors)
