@@ -13,6 +13,10 @@
 // taps that are broadcast LDS reads.  Boundary handling is a select on the LDS value, never a branch.
 #include "lfgc_common.h"
 
+#ifndef LFGC_WAVELET_ABLATE
+#define LFGC_WAVELET_ABLATE 0          // diagnostics (tools/ablate_wavelet.py): 1 no output stores, 2 no arithmetic, 4 no staging loads
+#endif
+
 namespace {
 
 struct IdwtArgs {
@@ -38,7 +42,8 @@ __device__ __forceinline__ float drop_value(float x, float m, float thr, bool st
     return __fadd_rn(__fsub_rn(__fmul_rn(x, hard), soft), soft);
 }
 
-constexpr int kTileCells = 128;      // cells of the flattened (y,x) plane per z-slice of a workgroup
+constexpr int kTileCells = 128;      // analysis: cells of the flattened (y,x) plane per z-slice of a workgroup
+constexpr int kFwdCells = 256;       // synthesis: plane cells per workgroup (one per thread, both z-slices each)
 
 // Synthesis: out_full[o] = sum_{s,t} in[s][i] F_s[t], o = 2 i + t per axis.  Thread = cell jj in [0,d] per axis:
 // it produces the 2x2x2 outputs o = 2 jj + p from the cells i = jj - e (e in {0,1}) with taps t = p + 2 e.
@@ -58,12 +63,8 @@ __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
         for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
     const int n0 = a.d0 + 1, n1 = a.d1 + 1, n2 = a.d2 + 1;
     const int plane_cells = n1 * n2;
-    const int tiles = (plane_cells + kTileCells - 1) / kTileCells, ztiles = (n0 + 1) / 2;
-    int b = blockIdx.x;
-    const int pt = b % tiles; b /= tiles;
-    const int zt = b % ztiles;
-    const int c = b / ztiles;
-    const int f0 = pt * kTileCells, jz0 = zt * 2;
+    const int pt = blockIdx.x, zt = blockIdx.y, c = blockIdx.z;     // 3-D grid: no index divisions
+    const int f0 = pt * kFwdCells, jz0 = zt * 2;
     const int chunk0 = (f0 / n2 - 1) * a.d2 - 1;
     const int len = a.len;
     const int dplane = a.d1 * a.d2;
@@ -80,9 +81,9 @@ __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
             const int iz = jz0 - 1 + zl;
             const bool ok = in_plane && iz >= 0 && iz < a.d0;
             const int o = ok ? iz * dplane + off : 0;
-            r[zl][0] = lc[o];
+            r[zl][0] = (LFGC_WAVELET_ABLATE & 4) ? (float)o : lc[o];
 #pragma unroll
-            for (int sb = 1; sb < 8; ++sb) r[zl][sb] = hc[(sb - 1) * dvol + o];
+            for (int sb = 1; sb < 8; ++sb) r[zl][sb] = (LFGC_WAVELET_ABLATE & 4) ? (float)(o + sb) : hc[(sb - 1) * dvol + o];
             if (DROP) {
                 if (a.mul_l) r[zl][0] = drop_value(r[zl][0], a.mul_l[o], a.thr_l, a.thr_l == a.thr_l);
                 if (a.mul_h) {
@@ -102,89 +103,110 @@ __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
         }
     }
     __syncthreads();
-    const int zl_t = threadIdx.x >> 7;
-    const int f = f0 + (threadIdx.x & (kTileCells - 1));
-    const int jz = jz0 + zl_t;
-    const bool valid = f < plane_cells && jz < n0;
+    // thread = one cell of the (y,x) plane, for BOTH z-slices of the workgroup: the index arithmetic, the x-range
+    // selects' predicates and the middle z-plane's 4 neighbour records are shared by its two output cells
+    const int f = f0 + threadIdx.x;
+    const bool in_plane = f < plane_cells;
     const int fc = min(f, plane_cells - 1);
     const int jy = fc / n2, jx = fc - jy * n2;
     const int k00 = jy * a.d2 + jx - chunk0;
-    float v[8][8];                                       // [e = ez*4+ey*2+ex][band]
+    const bool xok0 = jx < a.d2, xok1 = jx >= 1;
+    auto load_plane = [&](int zl, float (&P)[4][8]) {       // P[q = ey*2+ex][band] of z-plane zl
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int ez = e >> 2, ey = (e >> 1) & 1, ex = e & 1;
-        const bool xok = ex ? jx >= 1 : jx < a.d2;
-        const float* rec = s_v + ((zl_t + 1 - ez) * len + k00 - ey * a.d2 - ex) * kRec;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(rec);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(rec + 4);
-        v[e][0] = xok ? lo.x : 0.0f; v[e][1] = xok ? lo.y : 0.0f; v[e][2] = xok ? lo.z : 0.0f; v[e][3] = xok ? lo.w : 0.0f;
-        v[e][4] = xok ? hi.x : 0.0f; v[e][5] = xok ? hi.y : 0.0f; v[e][6] = xok ? hi.z : 0.0f; v[e][7] = xok ? hi.w : 0.0f;
-    }
-    float* outc = a.out + (long long)c * a.t0 * a.t1 * a.t2;
-    auto store = [&](int p, float val) {
-        const int oz = 2 * jz + (p >> 2) - a.o0, oy = 2 * jy + ((p >> 1) & 1) - a.o1, ox = 2 * jx + (p & 1) - a.o2;
-        if (valid && oz >= 0 && oz < a.t0 && oy >= 0 && oy < a.t1 && ox >= 0 && ox < a.t2)
-            outc[(oz * a.t1 + oy) * a.t2 + ox] = val;
+        for (int q = 0; q < 4; ++q) {
+            const bool xok = (q & 1) ? xok1 : xok0;
+            const float* rec = s_v + (zl * len + k00 - (q >> 1) * a.d2 - (q & 1)) * kRec;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(rec);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(rec + 4);
+            P[q][0] = xok ? lo.x : 0.0f; P[q][1] = xok ? lo.y : 0.0f; P[q][2] = xok ? lo.z : 0.0f; P[q][3] = xok ? lo.w : 0.0f;
+            P[q][4] = xok ? hi.x : 0.0f; P[q][5] = xok ? hi.y : 0.0f; P[q][6] = xok ? hi.z : 0.0f; P[q][7] = xok ? hi.w : 0.0f;
+        }
     };
-    if (SEP) {
-        // F_s[tz][ty][tx] = T[sz][tz] T[sy][ty] T[sx][tx]: contract x, then y, then z in registers (224 FMAs instead
-        // of 512, no filter traffic).  Tap of output parity p and neighbour e along one axis: t = p + 2 e.
-        float X[2][2][2][2][2];                           // [ez][ey][sz][sy][px]
+    float* outc = a.out + (long long)c * a.t0 * a.t1 * a.t2;
+    // one output cell jz from its neighbour planes: E0 = plane iz = jz (ez = 0), E1 = plane iz = jz - 1 (ez = 1)
+    auto cell = [&](int jz, const float (&E0)[4][8], const float (&E1)[4][8]) {
+        const bool valid = in_plane && jz < n0;
+        auto V = [&](int e, int sb) -> float { return (e >> 2) ? E1[e & 3][sb] : E0[e & 3][sb]; };
+        auto store = [&](int p, float val) {
+            const int oz = 2 * jz + (p >> 2) - a.o0, oy = 2 * jy + ((p >> 1) & 1) - a.o1, ox = 2 * jx + (p & 1) - a.o2;
+            if (valid && oz >= 0 && oz < a.t0 && oy >= 0 && oy < a.t1 && ox >= 0 && ox < a.t2) {
+                if (!(LFGC_WAVELET_ABLATE & 1) || val == 1.2345e-30f) outc[(oz * a.t1 + oy) * a.t2 + ox] = val;
+            }
+        };
+        if (LFGC_WAVELET_ABLATE & 2) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int ez = q >> 3, ey = (q >> 2) & 1, sz = (q >> 1) & 1, sy = q & 1;
-#pragma unroll
-            for (int px = 0; px < 2; ++px) {
+            for (int p = 0; p < 8; ++p) {
                 float t = 0.0f;
 #pragma unroll
-                for (int ex = 0; ex < 2; ++ex)
+                for (int s8 = 0; s8 < 8; ++s8) t += V(p, s8);
+                store(p, t);
+            }
+        } else if (SEP) {
+            // F_s[tz][ty][tx] = T[sz][tz] T[sy][ty] T[sx][tx]: contract x, then y, then z in registers (224 FMAs
+            // instead of 512, no filter traffic).  Tap of output parity p and neighbour e along one axis: t = p + 2 e.
+            float X[2][2][2][2][2];                           // [ez][ey][sz][sy][px]
 #pragma unroll
-                    for (int sx = 0; sx < 2; ++sx)
-                        t = __builtin_fmaf(v[ez * 4 + ey * 2 + ex][sz * 4 + sy * 2 + sx], a.taps[sx * 4 + px + 2 * ex], t);
-                X[ez][ey][sz][sy][px] = t;
+            for (int q = 0; q < 16; ++q) {
+                const int ez = q >> 3, ey = (q >> 2) & 1, sz = (q >> 1) & 1, sy = q & 1;
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int ex = 0; ex < 2; ++ex)
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx)
+                            t = __builtin_fmaf(V(ez * 4 + ey * 2 + ex, sz * 4 + sy * 2 + sx), a.taps[sx * 4 + px + 2 * ex], t);
+                    X[ez][ey][sz][sy][px] = t;
+                }
+            }
+            float Y[2][2][2][2];                              // [ez][sz][py][px]
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ez = q >> 3, sz = (q >> 2) & 1, py = (q >> 1) & 1, px = q & 1;
+                float t = 0.0f;
+#pragma unroll
+                for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+                    for (int sy = 0; sy < 2; ++sy)
+                        t = __builtin_fmaf(X[ez][ey][sz][sy][px], a.taps[sy * 4 + py + 2 * ey], t);
+                Y[ez][sz][py][px] = t;
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
+                float t = 0.0f;
+#pragma unroll
+                for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+                    for (int sz = 0; sz < 2; ++sz)
+                        t = __builtin_fmaf(Y[ez][sz][py][px], a.taps[sz * 4 + pz + 2 * ez], t);
+                store(p, t);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
+                float acc = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int tap = ((pz + 2 * (e >> 2)) * 4 + (py + 2 * ((e >> 1) & 1))) * 4 + (px + 2 * (e & 1));
+                    const f32x4 f0v = *reinterpret_cast<const f32x4*>(s_f + tap * 8);
+                    const f32x4 f1v = *reinterpret_cast<const f32x4*>(s_f + tap * 8 + 4);
+                    acc = __builtin_fmaf(V(e, 0), f0v.x, acc); acc = __builtin_fmaf(V(e, 1), f0v.y, acc);
+                    acc = __builtin_fmaf(V(e, 2), f0v.z, acc); acc = __builtin_fmaf(V(e, 3), f0v.w, acc);
+                    acc = __builtin_fmaf(V(e, 4), f1v.x, acc); acc = __builtin_fmaf(V(e, 5), f1v.y, acc);
+                    acc = __builtin_fmaf(V(e, 6), f1v.z, acc); acc = __builtin_fmaf(V(e, 7), f1v.w, acc);
+                }
+                store(p, acc);      // stored per parity: keeps the filter reads of later parities from being hoisted
             }
         }
-        float Y[2][2][2][2];                              // [ez][sz][py][px]
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int ez = q >> 3, sz = (q >> 2) & 1, py = (q >> 1) & 1, px = q & 1;
-            float t = 0.0f;
-#pragma unroll
-            for (int ey = 0; ey < 2; ++ey)
-#pragma unroll
-                for (int sy = 0; sy < 2; ++sy)
-                    t = __builtin_fmaf(X[ez][ey][sz][sy][px], a.taps[sy * 4 + py + 2 * ey], t);
-            Y[ez][sz][py][px] = t;
-        }
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
-            float t = 0.0f;
-#pragma unroll
-            for (int ez = 0; ez < 2; ++ez)
-#pragma unroll
-                for (int sz = 0; sz < 2; ++sz)
-                    t = __builtin_fmaf(Y[ez][sz][py][px], a.taps[sz * 4 + pz + 2 * ez], t);
-            store(p, t);
-        }
-    } else {
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
-            float acc = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int tap = ((pz + 2 * (e >> 2)) * 4 + (py + 2 * ((e >> 1) & 1))) * 4 + (px + 2 * (e & 1));
-                const f32x4 f0v = *reinterpret_cast<const f32x4*>(s_f + tap * 8);
-                const f32x4 f1v = *reinterpret_cast<const f32x4*>(s_f + tap * 8 + 4);
-                acc = __builtin_fmaf(v[e][0], f0v.x, acc); acc = __builtin_fmaf(v[e][1], f0v.y, acc);
-                acc = __builtin_fmaf(v[e][2], f0v.z, acc); acc = __builtin_fmaf(v[e][3], f0v.w, acc);
-                acc = __builtin_fmaf(v[e][4], f1v.x, acc); acc = __builtin_fmaf(v[e][5], f1v.y, acc);
-                acc = __builtin_fmaf(v[e][6], f1v.z, acc); acc = __builtin_fmaf(v[e][7], f1v.w, acc);
-            }
-            store(p, acc);          // stored per parity: keeps the filter reads of later parities from being hoisted
-        }
-    }
+    };
+    float PA[4][8], PB[4][8];
+    load_plane(1, PA);
+    load_plane(0, PB);
+    cell(jz0, PA, PB);              // outputs of cell jz0: planes jz0 (ez = 0) and jz0 - 1 (ez = 1)
+    load_plane(2, PB);
+    cell(jz0 + 1, PB, PA);          // cell jz0 + 1: planes jz0 + 1 and jz0
 }
 
 // Analysis-form kernel shared by the IDWT adjoint and the forward DWT:
@@ -225,11 +247,7 @@ __global__ __launch_bounds__(256) void analysis_kernel(const AnalysisArgs a) {
     if (!SEP)
         for (int i = threadIdx.x; i < 512; i += 256) s_f[(i & 63) * 8 + (i >> 6)] = a.filt[i];
     const int plane_cells = a.d1 * a.d2;
-    const int tiles = (plane_cells + kTileCells - 1) / kTileCells, ztiles = (a.d0 + 1) / 2;
-    int b = blockIdx.x;
-    const int pt = b % tiles; b /= tiles;
-    const int zt = b % ztiles;
-    const int c = b / ztiles;
+    const int pt = blockIdx.x, zt = blockIdx.y, c = blockIdx.z;     // 3-D grid: no index divisions
     const int f0 = pt * kTileCells, iz0 = zt * 2;
     const int chunk0 = (2 * (f0 / a.d2) - a.lo1) * a.n2 - a.lo2;
     const int len = a.len;
@@ -416,14 +434,14 @@ inline int check_level(const void* a, const void* b, const void* c, const void* 
 }
 
 template <typename K, typename A>
-int launch_tiled(K kern, int* lds_limit, const A& a, long long blocks, int lds_bytes, hipStream_t stream) {
-    if (blocks > 0x7fffffffLL || lds_bytes > 160 * 1024) return LFGC_E_UNSUPPORTED;
+int launch_tiled(K kern, int* lds_limit, const A& a, dim3 blocks, int lds_bytes, hipStream_t stream) {
+    if (blocks.y > 65535u || blocks.z > 65535u || lds_bytes > 160 * 1024) return LFGC_E_UNSUPPORTED;
     if (lds_bytes > 64 * 1024 && lds_bytes > *lds_limit) {      // raised once per kernel: launches stay graph-capturable
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
         *lds_limit = lds_bytes;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL(kern, blocks, dim3(256), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }
@@ -432,9 +450,11 @@ int launch_idwt(IdwtArgs a, bool drop, const float* taps, hipStream_t stream) {
     if (taps) for (int i = 0; i < 8; ++i) a.taps[i] = taps[i];
     a.o0 = (2 * a.d0 + 2 - a.t0) / 2; a.o1 = (2 * a.d1 + 2 - a.t1) / 2; a.o2 = (2 * a.d2 + 2 - a.t2) / 2;
     const int n0 = a.d0 + 1, n1 = a.d1 + 1, n2 = a.d2 + 1;
-    const int span = (kTileCells + n2 - 2) / n2;            // rows a run of 128 cells can straddle beyond its first
+    const int span = (kFwdCells + n2 - 2) / n2;             // rows a run of 256 cells can straddle beyond its first
     a.len = (span + 2) * a.d2 + 2;
-    const long long blocks = (long long)a.C * ((n0 + 1) / 2) * (((long long)n1 * n2 + kTileCells - 1) / kTileCells);
+    const long long ptiles = ((long long)n1 * n2 + kFwdCells - 1) / kFwdCells;
+    if (ptiles > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
+    const dim3 blocks((unsigned)ptiles, (unsigned)((n0 + 1) / 2), (unsigned)a.C);
     const int lds = (512 + 3 * a.len * kRec) * 4;
     if ((long long)a.d0 * a.d1 * a.d2 > 0x7fffffffLL / 8 || (long long)a.t0 * a.t1 * a.t2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
     static int lim[4] = {0, 0, 0, 0};
@@ -448,7 +468,9 @@ int launch_analysis(AnalysisArgs a, bool drop, const float* taps, hipStream_t st
     if (taps) for (int i = 0; i < 8; ++i) a.taps[i] = taps[i];
     const int span = (kTileCells + a.d2 - 2) / a.d2;
     a.len = (2 * span + 3) * a.n2 + 2 * a.d2 + 2;
-    const long long blocks = (long long)a.C * ((a.d0 + 1) / 2) * (((long long)a.d1 * a.d2 + kTileCells - 1) / kTileCells);
+    const long long ptiles = ((long long)a.d1 * a.d2 + kTileCells - 1) / kTileCells;
+    if (ptiles > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
+    const dim3 blocks((unsigned)ptiles, (unsigned)((a.d0 + 1) / 2), (unsigned)a.C);
     const int lds = (512 + 6 * a.len) * 4;
     if ((long long)a.n0 * a.n1 * a.n2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
     static int lim[4] = {0, 0, 0, 0};
