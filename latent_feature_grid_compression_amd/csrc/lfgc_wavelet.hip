@@ -6,7 +6,7 @@
 //   lfgc_grid_layout_f32          channel-first <-> channel-last conversion of the dense grid (the sampler and the
 //                                 gradient scatter work channel-last, the stencils channel-first)
 // All of them are byte movers with a 64-FMA-per-output stencil (no contraction worth an MFMA).  Both stencils share
-// one shape: a workgroup owns 2 z-slices x 128 consecutive cells of the flattened (y,x) plane of ONE channel, copies
+// one shape: a workgroup owns 2 z-slices of a run of consecutive cells of the flattened (y,x) plane of ONE channel, copies
 // the input neighbourhood of those cells into LDS as plain contiguous chunks of the source rows (every source value
 // is fetched from memory once per workgroup instead of once per reading thread: the per-thread version was bound by
 // the 64 vector-load instructions each thread issued), then every thread forms its 8 results from LDS with filter
