@@ -26,6 +26,7 @@ struct IdwtArgs {
     float* out;         // (C, t0,t1,t2)
     int C, d0, d1, d2, t0, t1, t2, o0, o1, o2;   // o = crop offset floor((2d+2-t)/2)
     int len;            // plane offsets per staged z-plane
+    int zchunk;         // sliding-window kernel: output z-slices per workgroup
     float taps[8];      // SEP build: the 1-D bank the filter is the outer product of: [low | high][tap]
     // DROP build only: the pruning layers' per-coefficient factors, shared by all channels
     const float* mul_l; // (d0,d1,d2) or NULL
@@ -207,6 +208,148 @@ __global__ __launch_bounds__(256) void idwt_level_kernel(const IdwtArgs a) {
     cell(jz0, PA, PB);              // outputs of cell jz0: planes jz0 (ez = 0) and jz0 - 1 (ez = 1)
     load_plane(2, PB);
     cell(jz0 + 1, PB, PA);          // cell jz0 + 1: planes jz0 + 1 and jz0
+}
+
+// Synthesis with a SLIDING WINDOW along z (separable filters): a workgroup keeps its 256 plane cells and walks `zchunk`
+// output slices; output slice jz needs the coefficient planes jz and jz - 1 only, so each step stages ONE new plane (the
+// tiled kernel above stages 3 planes per 2 slices), into a 2-slot LDS ring with one barrier per step, and the loads of
+// plane jz + 1 are issued right after the barrier so that they fly under the arithmetic of slice jz.  A thread keeps the
+// 4 neighbour records of plane jz in registers: they are the ez = 1 operands of the next step.
+template <bool DROP, int KI>
+__global__ __launch_bounds__(256) void idwt_slide_kernel(const IdwtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    float* s_v = s_dyn;                                   // ring[2][len][kRec]: a plane is read from LDS only in its own step
+    const int n0 = a.d0 + 1, n1 = a.d1 + 1, n2 = a.d2 + 1;
+    const int plane_cells = n1 * n2;
+    const int pt = blockIdx.x, c = blockIdx.z;
+    const int jz_begin = blockIdx.y * a.zchunk, jz_end = min(jz_begin + a.zchunk, n0);
+    const int f0 = pt * kFwdCells;
+    const int chunk0 = (f0 / n2 - 1) * a.d2 - 1;
+    const int len = a.len;
+    const int dplane = a.d1 * a.d2;
+    const int dvol = dplane * a.d0;
+    const float* lc = a.lll + (long long)c * dvol;
+    const float* hc = a.hf + (long long)c * 7 * dvol;
+
+    auto load_plane = [&](int iz, float (&r)[KI][8]) {    // plane iz of the 8 bands -> registers (zeros outside the level)
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int kk = threadIdx.x + 256 * i;
+            const int off = chunk0 + kk;
+            const bool ok = kk < len && off >= 0 && off < dplane && iz >= 0 && iz < a.d0;
+            const int o = ok ? iz * dplane + off : 0;
+            r[i][0] = lc[o];
+#pragma unroll
+            for (int sb = 1; sb < 8; ++sb) r[i][sb] = hc[(sb - 1) * dvol + o];
+            if (DROP) {
+                if (a.mul_l) r[i][0] = drop_value(r[i][0], a.mul_l[o], a.thr_l, a.thr_l == a.thr_l);
+                if (a.mul_h) {
+#pragma unroll
+                    for (int sb = 1; sb < 8; ++sb)
+                        r[i][sb] = drop_value(r[i][sb], a.mul_h[(sb - 1) * dvol + o], a.thr_h, a.thr_h == a.thr_h);
+                }
+            }
+#pragma unroll
+            for (int sb = 0; sb < 8; ++sb) r[i][sb] = ok ? r[i][sb] : 0.0f;
+        }
+    };
+    auto write_plane = [&](int slot, const float (&r)[KI][8]) {
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int kk = threadIdx.x + 256 * i;
+            if (kk < len) {
+                float* rec = s_v + (slot * len + kk) * kRec;
+                *reinterpret_cast<f32x4*>(rec) = f32x4{r[i][0], r[i][1], r[i][2], r[i][3]};
+                *reinterpret_cast<f32x4*>(rec + 4) = f32x4{r[i][4], r[i][5], r[i][6], r[i][7]};
+            }
+        }
+    };
+
+    const int f = f0 + threadIdx.x;
+    const bool in_plane = f < plane_cells;
+    const int fc = min(f, plane_cells - 1);
+    const int jy = fc / n2, jx = fc - jy * n2;
+    const int k00 = jy * a.d2 + jx - chunk0;
+    const bool xok0 = jx < a.d2, xok1 = jx >= 1;
+    auto read_records = [&](int slot, float (&P)[4][8]) {  // P[q = ey*2+ex][band]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool xok = (q & 1) ? xok1 : xok0;
+            const float* rec = s_v + (slot * len + k00 - (q >> 1) * a.d2 - (q & 1)) * kRec;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(rec);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(rec + 4);
+            P[q][0] = xok ? lo.x : 0.0f; P[q][1] = xok ? lo.y : 0.0f; P[q][2] = xok ? lo.z : 0.0f; P[q][3] = xok ? lo.w : 0.0f;
+            P[q][4] = xok ? hi.x : 0.0f; P[q][5] = xok ? hi.y : 0.0f; P[q][6] = xok ? hi.z : 0.0f; P[q][7] = xok ? hi.w : 0.0f;
+        }
+    };
+    float* outc = a.out + (long long)c * a.t0 * a.t1 * a.t2;
+    auto cell = [&](int jz, const float (&E0)[4][8], const float (&E1)[4][8]) {     // E0: plane jz, E1: plane jz - 1
+        auto V = [&](int e, int sb) -> float { return (e >> 2) ? E1[e & 3][sb] : E0[e & 3][sb]; };
+        float X[2][2][2][2][2];                               // [ez][ey][sz][sy][px]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ez = q >> 3, ey = (q >> 2) & 1, sz = (q >> 1) & 1, sy = q & 1;
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                float t = 0.0f;
+#pragma unroll
+                for (int ex = 0; ex < 2; ++ex)
+#pragma unroll
+                    for (int sx = 0; sx < 2; ++sx)
+                        t = __builtin_fmaf(V(ez * 4 + ey * 2 + ex, sz * 4 + sy * 2 + sx), a.taps[sx * 4 + px + 2 * ex], t);
+                X[ez][ey][sz][sy][px] = t;
+            }
+        }
+        float Y[2][2][2][2];                                  // [ez][sz][py][px]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int ez = q >> 3, sz = (q >> 2) & 1, py = (q >> 1) & 1, px = q & 1;
+            float t = 0.0f;
+#pragma unroll
+            for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+                for (int sy = 0; sy < 2; ++sy)
+                    t = __builtin_fmaf(X[ez][ey][sz][sy][px], a.taps[sy * 4 + py + 2 * ey], t);
+            Y[ez][sz][py][px] = t;
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int pz = p >> 2, py = (p >> 1) & 1, px = p & 1;
+            float t = 0.0f;
+#pragma unroll
+            for (int ez = 0; ez < 2; ++ez)
+#pragma unroll
+                for (int sz = 0; sz < 2; ++sz)
+                    t = __builtin_fmaf(Y[ez][sz][py][px], a.taps[sz * 4 + pz + 2 * ez], t);
+            const int oz = 2 * jz + pz - a.o0, oy = 2 * jy + py - a.o1, ox = 2 * jx + px - a.o2;
+            if (in_plane && oz >= 0 && oz < a.t0 && oy >= 0 && oy < a.t1 && ox >= 0 && ox < a.t2)
+                outc[(oz * a.t1 + oy) * a.t2 + ox] = t;
+        }
+    };
+
+    float r[KI][8];
+    float PA[4][8], PB[4][8];
+    load_plane(jz_begin - 1, r);
+    write_plane((jz_begin + 1) & 1, r);                   // slot of plane jz_begin - 1
+    load_plane(jz_begin, r);
+    __syncthreads();
+    read_records((jz_begin + 1) & 1, PB);                 // plane jz_begin - 1: the first step's ez = 1 operands
+    // two steps per trip so that the register sets alternate roles without copies
+#pragma unroll 1
+    for (int jz = jz_begin; jz < jz_end; jz += 2) {
+        write_plane(jz & 1, r);
+        __syncthreads();
+        if (jz + 1 < jz_end) load_plane(jz + 1, r);       // in flight under this slice's arithmetic
+        read_records(jz & 1, PA);
+        cell(jz, PA, PB);
+        if (jz + 1 < jz_end) {
+            write_plane((jz + 1) & 1, r);
+            __syncthreads();
+            if (jz + 2 < jz_end) load_plane(jz + 2, r);
+            read_records((jz + 1) & 1, PB);
+            cell(jz + 1, PB, PA);
+        }
+    }
 }
 
 // Analysis-form kernel shared by the IDWT adjoint and the forward DWT:
@@ -458,6 +601,21 @@ int launch_idwt(IdwtArgs a, bool drop, const float* taps, hipStream_t stream) {
     const int lds = (512 + 3 * a.len * kRec) * 4;
     if ((long long)a.d0 * a.d1 * a.d2 > 0x7fffffffLL / 8 || (long long)a.t0 * a.t1 * a.t2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
     static int lim[4] = {0, 0, 0, 0};
+    const int ki = (a.len + 255) / 256;
+    if (taps && ki <= 3) {                                   // separable filter: sliding window along z
+        a.zchunk = n0 < 6 ? n0 : 5;
+        const dim3 sblocks((unsigned)ptiles, (unsigned)((n0 + a.zchunk - 1) / a.zchunk), (unsigned)a.C);
+        const int slds = 2 * a.len * kRec * 4;
+        static int slim[6] = {0, 0, 0, 0, 0, 0};
+        if (drop) {
+            if (ki == 1) return launch_tiled(idwt_slide_kernel<true, 1>, &slim[0], a, sblocks, slds, stream);
+            if (ki == 2) return launch_tiled(idwt_slide_kernel<true, 2>, &slim[1], a, sblocks, slds, stream);
+            return launch_tiled(idwt_slide_kernel<true, 3>, &slim[2], a, sblocks, slds, stream);
+        }
+        if (ki == 1) return launch_tiled(idwt_slide_kernel<false, 1>, &slim[3], a, sblocks, slds, stream);
+        if (ki == 2) return launch_tiled(idwt_slide_kernel<false, 2>, &slim[4], a, sblocks, slds, stream);
+        return launch_tiled(idwt_slide_kernel<false, 3>, &slim[5], a, sblocks, slds, stream);
+    }
     if (taps) return drop ? launch_tiled(idwt_level_kernel<true, true>, &lim[3], a, blocks, lds, stream)
                           : launch_tiled(idwt_level_kernel<false, true>, &lim[2], a, blocks, lds, stream);
     return drop ? launch_tiled(idwt_level_kernel<true, false>, &lim[1], a, blocks, lds, stream)
