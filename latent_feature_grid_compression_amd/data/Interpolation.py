@@ -17,3 +17,23 @@ def trilinear_mse_loss(pred, p, f, min_bb, max_bb, res):
     :127) as one fused HIP pass: same ground truth bit for bit, fp64-accumulated mean, analytic gradient to ``pred``."""
     host = lambda v: v.detach().cpu().tolist() if torch.is_tensor(v) else list(v)
     return ops.gt_mse_loss(pred, p, f, host(min_bb), host(max_bb), host(res))
+
+
+def finite_difference_trilinear_grad(p, f, min_bb, max_bb, res, scale=None):
+    """Central finite differences of the ground-truth sampler (data/Interpolation.py:47-84): one lattice step to either
+    side per axis, clamped to the bounding box; ``scale`` (3,) optionally rescales the step lengths.  The six shifted
+    position sets go through ONE launch of the sampler kernel.  Returns (N, 3)."""
+    n = p.shape[0]
+    mn, mx, rs = (v.to(p.device, torch.float32) for v in (min_bb, max_bb, res))
+    step = (mx - mn) / (rs - 1)
+    shifted = p.unsqueeze(0).repeat(6, 1, 1)                       # [x-, x+, y-, y+, z-, z+]
+    for a in range(3):
+        shifted[2 * a, :, a] = torch.maximum(p[:, a] - step[a], mn[a])
+        shifted[2 * a + 1, :, a] = torch.minimum(p[:, a] + step[a], mx[a])
+    vals = trilinear_f_interpolation(shifted.reshape(-1, 3), f, min_bb, max_bb, res).view(6, n)
+    cols = []
+    for a in range(3):
+        width = shifted[2 * a + 1, :, a] - shifted[2 * a, :, a]
+        diff = 2 * width / (mx[a] - mn[a]) if scale is None else 2 * scale[a].to(p.device) * width / (mx[a] - mn[a])
+        cols.append((vals[2 * a + 1] - vals[2 * a]) / diff)
+    return torch.stack(cols, 1)

@@ -222,6 +222,26 @@ def trilinear_f_interpolation(p, f, min_bb, max_bb, res):
 
 # ---- caller-side arithmetic that defines the inputs (harness counterpart) ----------
 
+def finite_difference_trilinear_grad(p, f, min_bb, max_bb, res, scale=None):
+    """data/Interpolation.py:47-84: central differences of trilinear_f_interpolation with one lattice step per axis,
+    steps clamped to the bounding box; optional per-axis scale of the step length.  (N,3)."""
+    step = (max_bb - min_bb) / (res - 1)
+    cols = []
+    for a in range(3):
+        lo, hi = p.clone(), p.clone()
+        lo[:, a] = p[:, a] - step[a]
+        hi[:, a] = p[:, a] + step[a]
+        lo[lo[:, a] < min_bb[a], a] = min_bb[a]
+        hi[hi[:, a] > max_bb[a], a] = max_bb[a]
+        if scale is None:
+            diff = 2 * (hi[:, a] - lo[:, a]) / (max_bb[a] - min_bb[a])
+        else:
+            diff = 2 * scale[a] * (hi[:, a] - lo[:, a]) / (max_bb[a] - min_bb[a])
+        cols.append((trilinear_f_interpolation(hi, f, min_bb, max_bb, res) -
+                     trilinear_f_interpolation(lo, f, min_bb, max_bb, res)) / diff)
+    return torch.cat([c.unsqueeze(1) for c in cols], 1)
+
+
 def normalize_volume(volume, min_v, max_v, min_n, max_n):
     """data/IndexDataset.py:7-8."""
     return (max_n - min_n) * ((volume - min_v) / (max_v - min_v)) + min_n

@@ -217,3 +217,12 @@ def test_trainstep(golden_dir):
         assert np.array_equal(weights[i].detach().numpy(), g['after.net_layers.%d.weight' % i])
         assert np.array_equal(biases[i].detach().numpy(), g['after.net_layers.%d.bias' % i])
     assert np.array_equal(weights[L].detach().numpy(), g['after.final_layer.weight'])
+
+
+def test_finite_difference_gradient(golden_dir):
+    g = load(golden_dir, 'gt_fd_grad.npz')
+    p, vol = torch.from_numpy(g['p']), torch.from_numpy(g['vol'])
+    mn, mx, rs = (torch.from_numpy(g[k]) for k in ('min_bb', 'max_bb', 'res'))
+    assert np.array_equal(R.finite_difference_trilinear_grad(p, vol, mn, mx, rs).numpy(), g['grad'])
+    assert np.array_equal(R.finite_difference_trilinear_grad(p, vol, mn, mx, rs, scale=torch.from_numpy(g['scale'])).numpy(),
+                          g['grad_scaled'])
