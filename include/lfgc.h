@@ -251,8 +251,11 @@ typedef struct lfgc_positions {
  *   LFGC_PRECISION_F32    v_mfma_f32_32x32x2_f32, bitwise an fp32 fmaf chain per output;
  *   LFGC_PRECISION_F16X2  every fp32 operand carried as an f16 pair hi + lo (22-24 significant bits), three
  *                         v_mfma_f32_32x32x16_f16 per product block with fp32 accumulation: same error level as the
- *                         fp32 build against the reference (fp32 summation order dominates), ~3x the throughput.
- *                         Needs |activations| < 65504.
+ *                         fp32 build against the reference (fp32 summation order dominates), several times the
+ *                         throughput.  Pre-activations are carried in turns of pi (weight images divided by pi at pack
+ *                         time) and SnakeAlt is evaluated with the hardware cosine.  Valid while |pre-activations| <~ 800
+ *                         and |grid features| < 65504; beyond that the affected outputs come out as NaN and *status is
+ *                         set -- see lfgc_forward_f32.
  *   LFGC_PRECISION_F16    REDUCED precision (opt-in, never the default; does not meet the 1e-5 parity bound): weights and
  *                         activations of the layer GEMMs rounded to f16 (weights pre-scaled per layer as above), ONE
  *                         v_mfma_f32_32x32x16_f16 per product block, fp32 accumulation, fp32 master parameters, fp32
@@ -272,10 +275,17 @@ typedef struct lfgc_positions {
  *   packed    device blob from lfgc_pack_mlp_f32
  *   out       device (N) fp32  (= the (N,1) result)
  *   stash     device, lfgc_stash_bytes(N) bytes, or NULL.  When given, the layer-0 input and every
- *             pre-activation are saved for lfgc_backward_f32 (private layout). */
+ *             pre-activation are saved for lfgc_backward_f32 (private layout).
+ *   status    device int32 or NULL (ignored by LFGC_PRECISION_F32).  The reference computes in fp32 and stays finite
+ *             for any finite parameters (model/Feature_Grid_Model.py:12-13, :72-75); the f16 builds have a range.
+ *             With status != NULL the call clears *status, the f16 kernel sets it to 1 if any sample left that range,
+ *             and the call then enqueues the same pass on the exact-fp32 build predicated on *status (its workgroups
+ *             return immediately when it is 0): `out` (and `stash`) always hold reference-equivalent results, without
+ *             a host synchronisation.  With status == NULL out-of-range samples are returned as NaN. */
 int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
                      const float* grid_cl, int D, int H, int W,
-                     const float* packed, int precision, int clamp, float* out, float* stash, lfgc_stream_t stream);
+                     const float* packed, int precision, int clamp, float* out, float* stash, int32_t* status,
+                     lfgc_stream_t stream);
 
 /* Backward of lfgc_forward_f32 (what autograd derives for model/Feature_Grid_Model.py:62-75;
  * triggered at training/training.py:137).  positions->pos must be non-NULL.

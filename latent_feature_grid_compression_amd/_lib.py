@@ -67,7 +67,7 @@ SIGNATURES = {
     'lfgc_stash_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'lfgc_pack_mlp_f32': (c_int, [POINTER(MlpDesc), _PP, _PP, c_void_p, c_void_p]),
     'lfgc_forward_f32': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
-                                 c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'lfgc_backward_workspace_bytes': (c_int64, [POINTER(MlpDesc), c_int64]),
     'lfgc_backward_f32': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p, _PP, _PP, c_void_p,
@@ -92,15 +92,18 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    build_error = None
     if not os.path.exists(LIB_PATH) and 'LFGC_LIB_PATH' not in os.environ:
         try:                                   # fresh checkout: build in-tree (hipcc, gfx950); still no CPU fallback
             from .build import build
             build(verbose=False)
-        except Exception:                      # noqa: BLE001
-            pass
+        except Exception as e:                 # noqa: BLE001 -- reported below, chained into the LfgcError
+            build_error = e
     if not os.path.exists(LIB_PATH):
         raise LfgcError('liblfgc.so not found at %s: build it with `python -m latent_feature_grid_compression_amd.build` '
-                        '(hipcc, gfx950). There is no CPU fallback for the HIP path.' % LIB_PATH)
+                        '(hipcc, gfx950). There is no CPU fallback for the HIP path.%s'
+                        % (LIB_PATH, '' if build_error is None else ' The in-tree build failed: %s' % build_error)
+                        ) from build_error
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
     constexpr int K0P16 = (K0P + 15) / 16 * 16;
     constexpr int HBLK0 = HP * (K0P16 + 4) + HP, HBLK1 = HP * (HP + 4) + HP;
     const int off_h = off_t + TB0 + (L - 1) * TB1;            // scales, then the f16-split forward blocks (lfgc_common.h)
-    const int off_img = H16 ? off_h + 16 + HBLK0 + (L - 1) * HBLK1 : off_t;
+    const int off_img = H16 ? off_h + 32 + LFGC_MAX_LAYERS * HP + HBLK0 + (L - 1) * HBLK1 : off_t;
     auto image_src = [&](int l) -> const float* {
         return l == 0 ? a.packed + off_img : a.packed + off_img + TB0 + (long long)(l - 1) * TB1;
     };
@@ -668,12 +668,13 @@ static __global__ __launch_bounds__(256) void lfgc_bwd_reduce_kernel(const LfgcR
 template <int CH, int MT, int NF, int WAVES, int PREC>
 static int lfgc_launch_bwd_data(const LfgcBwdArgs& a, int lds_bytes, int grid_data, hipStream_t stream) {
     auto kd = lfgc_bwd_data_kernel<CH, MT, NF, WAVES, PREC>;
-    static int lds_limit_set = 0;
-    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
+    static int lds_limit_set[LFGC_MAX_DEVICES] = {0};      // per (instantiation, device)
+    const int dev = lfgc_current_device();
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
-        lds_limit_set = lds_bytes;
+        lds_limit_set[dev] = lds_bytes;
     }
     hipLaunchKernelGGL(kd, dim3(grid_data), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();
@@ -700,12 +701,13 @@ static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int wav
         constexpr int TPWM = TPW0 > TPW1 ? TPW0 : TPW1;
         const int comb_bytes = 4 * TPWM * 17 * 64 * 4;
         auto kw = lfgc_bwd_weight_kernel<CH, MT, NF>;
-        static int comb_limit_set = 0;
-        if (comb_bytes > 64 * 1024 && comb_bytes > comb_limit_set) {
+        static int comb_limit_set[LFGC_MAX_DEVICES] = {0};
+        const int dev = lfgc_current_device();
+        if (comb_bytes > 64 * 1024 && comb_bytes > comb_limit_set[dev]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kw),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, comb_bytes);
             if (e != hipSuccess) return (int)e;
-            comb_limit_set = comb_bytes;
+            comb_limit_set[dev] = comb_bytes;
         }
         hipLaunchKernelGGL(kw, dim3(grid_w), dim3(512), comb_bytes, stream, w);
     }

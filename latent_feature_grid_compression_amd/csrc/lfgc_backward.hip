@@ -79,13 +79,7 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     w.stash = stash; w.dstash = dstash; w.d_out = d_out; w.n = n; w.ntiles = c.ntiles; w.L = p.L;
     w.slabs = slabs; w.slab_floats = lfgc_slab_floats(p);
 
-    static int cus = 0;                   // queried once
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-               prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
+    const int cus = lfgc_num_cus();       // per device
     // data kernel: one workgroup per CU, 8 waves once every CU gets a 256-sample batch, else 4 (tiles beyond the
     // last whole 128-sample group are never touched: the stash covers whole 256-sample groups, lfgc_stash_bytes)
     const int waves = ((n + 255) / 256 >= cus) ? 8 : 4;

@@ -11,17 +11,7 @@ int lfgc_fwd16_dispatch_ch24(int MT, const LfgcFwdArgs& a, int lds_bytes, int gr
 int lfgc_fwd16_dispatch_ch32(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
 
 namespace {
-int g_num_cus = 0;
-int num_cus() {
-    if (g_num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_num_cus = prop.multiProcessorCount;
-        if (g_num_cus <= 0) g_num_cus = 256;
-    }
-    return g_num_cus;
-}
+int num_cus() { return lfgc_num_cus(); }
 }  // namespace
 
 // Validates `positions` and fills the position part of the kernel arguments; returns the sample count
@@ -52,7 +42,7 @@ int lfgc_fill_positions(const lfgc_positions* ps, LfgcFwdArgs* a, long long* n_o
 extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
                                 const float* grid_cl, int D, int H, int W,
                                 const float* packed, int precision, int clamp, float* out, float* stash,
-                                lfgc_stream_t stream) {
+                                int32_t* status, lfgc_stream_t stream) {
     if (!desc || !positions || !grid_cl || !packed || !out) return LFGC_E_NULL;
     if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
     if (D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
@@ -72,9 +62,10 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     // whole 128-sample groups either way (lfgc_stash_bytes), so both builds write the same format.
     const bool h16 = precision != LFGC_PRECISION_F32;
     a.single = precision == LFGC_PRECISION_F16 ? 1 : 0;
+    a.status = nullptr; a.redo_if = nullptr;
     const int all_blocks = h16 ? p.blkh0 + (p.L - 1) * p.blkh1 : p.off_final;
     const int max_block = h16 ? (p.blkh0 > p.blkh1 ? p.blkh0 : p.blkh1) : (p.blk0 > p.blk1 ? p.blk0 : p.blk1);
-    const int fixed = p.HP + 4 + (h16 ? 16 : 0);        // [Wf | bf] (+ per-layer scales)
+    const int fixed = p.HP + 4 + (h16 ? 16 + LFGC_MAX_LAYERS * p.HP : 0);   // [Wf | bf] (+ per-layer scales + resident biases)
     a.resident = ((fixed + all_blocks) * 4 <= 80 * 1024) ? 1 : 0;
     int lds_bytes = (fixed + (a.resident ? all_blocks : 2 * max_block)) * 4;
     a.coord_table = 0;
@@ -91,13 +82,37 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     if (grid > a.nbatches) grid = a.nbatches;
     hipStream_t st = (hipStream_t)stream;
     if (h16) {
+        if (status) {                                   // range screen on: cleared here, set by the kernel (stream order)
+            const hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), st);
+            if (e != hipSuccess) return (int)e;
+            a.status = status;
+        }
+        int rc16;
         switch (p.CH) {
-            case 8: return lfgc_fwd16_dispatch_ch8(p.MT, a, lds_bytes, (int)grid, st);
-            case 16: return lfgc_fwd16_dispatch_ch16(p.MT, a, lds_bytes, (int)grid, st);
-            case 24: return lfgc_fwd16_dispatch_ch24(p.MT, a, lds_bytes, (int)grid, st);
-            case 32: return lfgc_fwd16_dispatch_ch32(p.MT, a, lds_bytes, (int)grid, st);
+            case 8: rc16 = lfgc_fwd16_dispatch_ch8(p.MT, a, lds_bytes, (int)grid, st); break;
+            case 16: rc16 = lfgc_fwd16_dispatch_ch16(p.MT, a, lds_bytes, (int)grid, st); break;
+            case 24: rc16 = lfgc_fwd16_dispatch_ch24(p.MT, a, lds_bytes, (int)grid, st); break;
+            case 32: rc16 = lfgc_fwd16_dispatch_ch32(p.MT, a, lds_bytes, (int)grid, st); break;
             default: return LFGC_E_UNSUPPORTED;
         }
+        if (rc16 != LFGC_OK || !status) return rc16;
+        // Range fallback: the same pass on the exact-fp32 build, enqueued behind the fast one; its workgroups return
+        // at once unless the fast kernel has set *status (a sample left the f16 range: diverged or very wide model).
+        // No host synchronisation, graph-capturable; costs one empty launch when nothing overflowed.
+        a.status = nullptr; a.redo_if = status; a.single = 0;
+        const int all32 = p.off_final, max32 = p.blk0 > p.blk1 ? p.blk0 : p.blk1, fixed32 = p.HP + 4;
+        a.resident = ((fixed32 + all32) * 4 <= 80 * 1024) ? 1 : 0;
+        lds_bytes = (fixed32 + (a.resident ? all32 : 2 * max32)) * 4;
+        a.coord_table = 0;
+        if (!a.pos) {
+            const long long tbl = 4LL * ((long long)a.res0 + a.res1 + a.res2);
+            const long long cap = a.resident ? 80 * 1024 : 160 * 1024;
+            if (lds_bytes + tbl <= cap) { a.coord_table = 1; lds_bytes += (int)tbl; }
+        }
+        a.waves = (!a.resident && (n + 255) / 256 >= num_cus()) ? 8 : 4;
+        a.nbatches = (n + 255) / 256 * (8 / a.waves);
+        grid = (a.resident ? 2LL : 1LL) * num_cus();
+        if (grid > a.nbatches) grid = a.nbatches;
     }
     switch (p.CH) {
         case 8: return lfgc_fwd_dispatch_ch8(p.MT, a, lds_bytes, (int)grid, st);

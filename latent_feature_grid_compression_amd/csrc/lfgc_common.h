@@ -8,6 +8,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LFGC_WAVE 64
+// f16-split forward (lfgc_forward16.h): activations handed to the next layer are multiplied by LFGC_ACT_SCALE so that
+// their f16 hi half overflows before the pre-activation leaves the domain of v_cos_f32 (|a / pi| <= 256):
+// s ((pi/2) 256 - 1) = 65582 > 65520 (rounds to inf), s ((pi/2) 250 + 1) = 64368 < 65504 (largest finite f16).
+// The value is chosen so that both constants of the scaled activation  s h = (s pi/2) t + s/2 - (s/2) cos(2 pi t)
+// are fp32 numbers: s pi/2 = LFGC_ACT_C exactly and s/2 = c/pi = LFGC_ACT_HALF to 1.8e-12 -- no systematic error in
+// the linear term (a rounded pi/2 would add 2.8e-8 |a|/2 to every activation with the same sign).
+#define LFGC_ACT_C 256.8191833496094f              // 0x1.00d1b6p+8
+#define LFGC_ACT_HALF 81.74808502197266f           // 0x1.46fe0ap+6 = LFGC_ACT_C / pi
+#define LFGC_ACT_SCALE 163.49617004365646          // double: LFGC_ACT_C / (pi / 2); divisor of the next layer's weight image
+#define LFGC_TURNS_MAX 255.0f            // last layer (no f16 conversion): explicit screen
 #define LFGC_TILE_SAMPLES 32          // samples per wave tile (N dimension of v_mfma_f32_32x32x2_f32)
 
 // ------------------------------------------------------------------------------------------------
@@ -35,7 +45,7 @@ struct LfgcPlan {
     // f16-split forward section (lfgc_forward16.h): per-layer power-of-two scales, then layer blocks whose rows
     // hold, per 16-column k-step, [lane half 0: 8 hi halfs | 8 lo halfs][lane half 1: 8 hi | 8 lo] (64 B), i.e.
     // 4 bytes per weight like the fp32 blocks, same +16 B row padding, followed by the scaled fp32 bias.
-    int K0P16, SH0, SH1, blkh0, blkh1, off_h, off_hblk;
+    int K0P16, SH0, SH1, blkh0, blkh1, off_h, off_hbias, off_hblk;
     int off_ht;              // f16-split TRANSPOSED images for the backward data chain (same sizes as tblk0 / tblk1)
 };
 
@@ -69,8 +79,12 @@ __host__ __device__ inline LfgcPlan lfgc_make_plan(int C, int H, int L, int NF) 
     p.SH1 = p.HP + 4;
     p.blkh0 = p.HP * p.SH0 + p.HP;
     p.blkh1 = p.HP * p.SH1 + p.HP;
-    p.off_h = p.off_t + p.tblk0 + (L - 1) * p.tblk1;         // 16 floats: scale[8] | 1/scale[8]
-    p.off_hblk = p.off_h + 16;
+    // 32 floats: scale[8] | 1/scale[8] of the transposed images (true W), then scale[8] | 1/scale[8] of the forward
+    // images (W / pi [/ LFGC_ACT_SCALE], lfgc_forward16.h); then the hidden-layer biases divided by pi, un-scaled,
+    // LFGC_MAX_LAYERS x HP (the f16-split forward adds them in its epilogue and keeps them LDS-resident)
+    p.off_h = p.off_t + p.tblk0 + (L - 1) * p.tblk1;
+    p.off_hbias = p.off_h + 32;
+    p.off_hblk = p.off_hbias + LFGC_MAX_LAYERS * p.HP;
     p.off_ht = p.off_hblk + p.blkh0 + (L - 1) * p.blkh1;
     p.total_floats = p.off_ht + p.tblk0 + (L - 1) * p.tblk1;
     p.stash_tile_floats = 64 * (p.KS0 + L * 16 * p.MT);
@@ -244,6 +258,24 @@ __device__ __forceinline__ float lfgc_snake_grad_t(float a) {
 // tensor-scalar multiply carried out in fp32 with the scalar cast to fp32 -> fp32(2^(k+1)) * fp32(pi).
 __device__ __forceinline__ float lfgc_freq(int k) {
     return (float)(2 << k) * 3.14159274101257324f;     // exact power of two times fp32(pi): one rounding, exact here
+}
+
+// Per-device host-side caches (CU count, one-time kernel attributes) are keyed by the current HIP device: a process may
+// drive several devices (the caller selects the device of its tensors before calling in; ops.py does).
+#define LFGC_MAX_DEVICES 16
+static inline int lfgc_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LFGC_MAX_DEVICES) dev = 0;
+    return dev;
+}
+static inline int lfgc_num_cus() {
+    static int cus[LFGC_MAX_DEVICES] = {0};
+    const int dev = lfgc_current_device();
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
 }
 
 #define LFGC_HIP_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

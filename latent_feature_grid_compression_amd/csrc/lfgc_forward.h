@@ -44,6 +44,8 @@ struct LfgcFwdArgs {
     int waves;                 // waves per workgroup of the chosen build (4 or 8)
     int coord_table;           // lattice mode: per-axis coordinate tables fit LDS (res0+res1+res2 floats)
     int single;                // f16 builds: 1 = single product W_hi.h_hi (LFGC_PRECISION_F16), 0 = hi/lo split
+    int* status;               // f16 builds: set to 1 when a sample left the range of the fast arithmetic (or nullptr)
+    const int* redo_if;        // exact build: run only if *redo_if != 0 (nullptr: always) -- the range fallback
 };
 
 // Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile
@@ -269,6 +271,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
     constexpr int EPH = EP / 2;          // scalar inputs carried per lane
     constexpr int NT = WAVES * 64;
 
+    if (a.redo_if && *a.redo_if == 0) return;            // range fallback of the f16 builds: nothing to redo (uniform)
+
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_final = smem;               // Wf (HP) | bf (4)
     float* s_w = smem + HP + 4;          // resident: every layer block; streamed: ring of 2 x BLKMAX
@@ -391,12 +395,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
 template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
 static int lfgc_launch_fwd_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
     auto kern = lfgc_fwd_kernel<CH, MT, NF, WAVES, STREAM, STASH>;
-    static int lds_limit_set = 0;          // per instantiation; raised once (also keeps launches graph-capturable)
-    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
+    static int lds_limit_set[LFGC_MAX_DEVICES] = {0};   // per (instantiation, device); raised once (launches stay graph-capturable)
+    const int dev = lfgc_current_device();
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
-        lds_limit_set = lds_bytes;
+        lds_limit_set[dev] = lds_bytes;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();

@@ -4,39 +4,73 @@
 // fp32 operand of the layer GEMMs is carried as an f16 pair x = hi + lo (hi = rne_f16(x), lo = rne_f16(x - hi):
 // 22-24 significant bits) and each fp32 product block is three v_mfma_f32_32x32x16_f16 with fp32 accumulation:
 //        W.h  ~=  W_hi.h_hi + W_hi.h_lo + W_lo.h_hi            (the dropped W_lo.h_lo term is <= 2^-22 relative)
-// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the f16 rate (measured 68 cycles per 4 kFLOP vs 34 cycles per 32
-// kFLOP, tools/microbench/mfma_interleave.hip), so three f16 MFMAs do the work of eight f32 ones in 96 instead of
-// 512 pipe cycles.  Measured end-to-end error vs the reference is at the level of the exact-fp32 build (fp32
-// accumulation order dominates; tests/test_hip_forward.py).
-// Range: weights are pre-scaled per layer by a power of two (pack_scale_kernel) so that hi/lo halves sit in the
-// middle of the f16 range; the accumulator is scaled back exactly.  Activations must stay below 65504 in magnitude
-// (f16 overflow -> inf/NaN); the exact build (precision 0) has no such limit.
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the f16 rate (64 cycles per 4 kFLOP vs 32 cycles per 32 kFLOP), so
+// three f16 MFMAs do the work of eight f32 ones in 96 instead of 512 pipe cycles.
 //
 // Register mapping: one wave = 32 samples; D/C layout of the 32x32x16 MFMA equals the 32x32x2 one, so the chain
 // "accumulators -> SnakeAlt -> next layer's B operand" is kept: accumulator registers 8s..8s+7 of tile m become, as
 // an f16x8 fragment, exactly the B operand of k-step 2m + s (the weight columns are stored in that k order).
+//
+// Pre-activations in TURNS OF PI.  The f16-split weight images and the biases of every hidden layer are stored
+// divided by pi (pack_kernel, in fp64 before the hi/lo split: no precision is lost against the split itself), so the
+// accumulator holds t = a / pi and
+//     SnakeAlt(a) = a/2 + sin(a)^2 = (pi/2) t + (1 - cos(2 pi t))/2,      cos(2 pi t) = v_cos_f32(t)
+// (the hardware cosine takes revolutions and reduces its argument exactly; its absolute error is 1.25e-7,
+// tools/microbench/hwcos_snake.hip): 4 VALU instructions per activation instead of 13 for Cody-Waite + polynomial.
+// v_cos_f32 is only valid for |t| <= 256: the activations handed to the next layer are multiplied by LFGC_ACT_SCALE
+// (folded into the constants: free; the next layer's weight image is divided by it), chosen so that their f16 hi
+// half overflows to inf before |t| reaches 256 (lfgc_common.h).  Such an overflow -- as any |grid feature| >= 65520 --
+// turns the sample's output into NaN; the kernel reports it through the status word (LfgcFwdArgs::status) and the host
+// entry answers by redoing the launch with the exact-fp32 build, whose range is fp32's (lfgc_capi_forward.hip).
+//
+// Issue schedule.  v_mfma_f32_32x32x16_f16 occupies the matrix pipe for 32 cycles and the SIMD's vector issue for 8 of
+// them; about five independent VALU instructions issue in its shadow (tools/microbench/mfma_shadow.hip: 32.0 -> 33.5
+// cycles per MFMA with 0 -> 5 fillers, +4.5 cycles for every further one; with two waves per SIMD the limit is the
+// same per MFMA).  Each layer therefore runs as one stream of "gaps" = one MFMA + one slice of other work, written
+// out gap by gap with a scheduling fence after each: the A-operand reads of the NEXT k-step (2 ds_read_b128), and one
+// third of the activation + hi/lo split of one accumulator PAIR of the PREVIOUS output tile (3-4 VALU).  The
+// activation of a layer's last tile rides under the first MFMAs of the next layer (whose last two k-steps are the
+// ones that need it).
 #pragma once
+#include <utility>
 #include "lfgc_forward.h"
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// x[0..8) fp32 -> hi / lo f16 fragments, 2 VALU instructions per value: one packed RNE conversion per pair for each
-// of hi and lo, and the remainder x - f32(hi) as ONE mixed-precision FMA per value (v_fma_mix_f32 reads the f16 half
-// in place: hi * -1 + x, exact).  (Plain C++ casts cost 4 per value: hipcc converts every hi half twice.)
+template <class F, int... I>
+__device__ __forceinline__ void lfgc_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression
+template <int N, class F>
+__device__ __forceinline__ void lfgc_static_for(F&& f) {
+    lfgc_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// hi = rne_f16 of a pair (one v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned lfgc_cvt_pk(float x0, float x1) {
+    f32x2 v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2));
+}
+// lo = rne_f16(x - f32(hi)) of a pair: ONE mixed-precision FMA per value that reads the f16 half in place and writes
+// its f16 result into the destination half (hi * -1 + x is exact in fp32, so the only rounding is the final one)
+__device__ __forceinline__ unsigned lfgc_lo_pk(unsigned h, float x0, float x1) {
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+    return l;
+}
+
+// x[0..8) fp32 -> hi / lo f16 fragments, 1.5 VALU instructions per value.
 __device__ __forceinline__ void lfgc_split8(const float* __restrict__ x, h16x8& hi, h16x8& lo) {
     u32x4 hp, lp;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        unsigned h, l;
-        float r0, r1;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x[2 * t]), "v"(x[2 * t + 1]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h), "v"(x[2 * t]));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h), "v"(x[2 * t + 1]));
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l) : "v"(r0), "v"(r1));
-        hp[t] = h;
-        lp[t] = l;
+        hp[t] = lfgc_cvt_pk(x[2 * t], x[2 * t + 1]);
+        lp[t] = lfgc_lo_pk(hp[t], x[2 * t], x[2 * t + 1]);
     }
     hi = __builtin_bit_cast(h16x8, hp);
     lo = __builtin_bit_cast(h16x8, lp);
@@ -46,88 +80,202 @@ __device__ __forceinline__ void lfgc_split8(const float* __restrict__ x, h16x8& 
 __device__ __forceinline__ void lfgc_cvt8(const float* __restrict__ x, h16x8& hi) {
     u32x4 hp;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        unsigned h;
-        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x[2 * t]), "v"(x[2 * t + 1]));
-        hp[t] = h;
-    }
+    for (int t = 0; t < 4; ++t) hp[t] = lfgc_cvt_pk(x[2 * t], x[2 * t + 1]);
     hi = __builtin_bit_cast(h16x8, hp);
 }
 
-// One hidden layer on a 32-sample tile.  LAST = false: outputs the next layer's fragments; LAST = true: folds the
-// final Linear (H -> 1) in and returns this lane's partial dot product through `ydot`.
-// SPLIT = false: single f16 product W_hi.h_hi (the lo halves of the weight images and of the activations are ignored).
-template <int KS16, int MT, int S, bool STASH, bool LAST, bool SPLIT>
-__device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk, const h16x8 (&Bhi)[KS16],
-                                                 const h16x8 (&Blo)[KS16], float inv_scale,
-                                                 h16x8 (&Ohi)[2 * MT], h16x8 (&Olo)[2 * MT],
-                                                 const float* __restrict__ s_final, float& ydot,
-                                                 float* __restrict__ stash, int j, int hh, int lane) {
-    const float* s_bias = s_blk + 32 * MT * S + 4 * hh;
-    const float* s_row = s_blk + j * S + 8 * hh;              // lane half hh: bytes [32 hh, 32 hh + 32) of each 64-B k-step
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        f32x16 acc;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(s_bias + 32 * m + 8 * q);
-            acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-        }
-        const float* arow = s_row + 32 * m * S;
-#pragma unroll
-        for (int ks = 0; ks < KS16; ++ks) {
-            const h16x8 whi = *reinterpret_cast<const h16x8*>(arow + 16 * ks);
-#if LFGC_ABLATE & 4
-            acc[ks & 15] += (float)whi[0] * (float)Bhi[ks][0];
-#else
-            if (SPLIT) {
-                const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, Bhi[ks], acc, 0, 0, 0);      // small terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Blo[ks], acc, 0, 0, 0);
+// Activation + hand-over of one finished 32-row output tile, cut into 8 accumulator pairs x 3 stages ("slots") so
+// that a slot fits the shadow of one MFMA.  Pair P = accumulator registers 2P, 2P+1 = rows 32m + 8(P>>1) + 4hh +
+// 2(P&1) + {0,1} of the lane's sample; it becomes 32-bit element P&3 of output fragment P>>2 of the tile.
+//   stage 0: t = acc / scale + b/pi (fma), first cosine            [bias quads stream through LDS reads one quad ahead]
+//   stage 1: second cosine, first result
+//   stage 2: second result, hi/lo split | head contribution (LAST)
+// The bounded part (1 - cos)/2 = sin(a)^2 is formed first and the linear part added last: the only rounding at the
+// magnitude of the result is the final one, like the reference's own 0.5 a + sin(a)^2.
+template <bool STASH, bool LAST, bool SPLIT>
+struct LfgcEpilogue {
+    float inv_scale;
+    const float* bias;        // LDS: b/pi of the tile's rows for this lane half (quad q at bias + 8 q)
+    const float* wf;          // LDS: final-layer weights of the same rows (LAST)
+    float* stash;             // this tile's stash rows for this lane, or nullptr
+    f32x4 bq[2], wq[2];
+    float t0, t1, c0, c1, h0, h1;
+
+    __device__ __forceinline__ void begin() {                 // issue the first bias quad (call >= 1 gap before slot 0)
+        bq[0] = *reinterpret_cast<const f32x4*>(bias);
+        if (LAST) wq[0] = *reinterpret_cast<const f32x4*>(wf);
+    }
+
+    template <int P, int S>
+    __device__ __forceinline__ void slot(const f32x16& acc, u32x4 (&Ohi)[2], u32x4 (&Olo)[2], float& ydot, float& tmax) {
+        constexpr int Q = P >> 1, I = 2 * (P & 1);
+        if constexpr (S == 0) {
+            if constexpr ((P & 1) == 0 && Q + 1 < 4) {
+                bq[(Q + 1) & 1] = *reinterpret_cast<const f32x4*>(bias + 8 * (Q + 1));
+                if (LAST) wq[(Q + 1) & 1] = *reinterpret_cast<const f32x4*>(wf + 8 * (Q + 1));
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, Bhi[ks], acc, 0, 0, 0);
-#endif
-        }
-        float av[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) av[r] = acc[r] * inv_scale;          // exact: power of two
-        if (STASH) {
-            float* pm = stash + m * (16 * 64) + lane;
-            asm volatile("" : "+v"(pm));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pm[r * 64] = av[r];
-        }
-        // no range screen here (the exact build has one): |a| > 2^15 means |h| ~ |a|/2 is about to leave the f16
-        // range this build requires anyway; the polynomial path stays finite and degrades gracefully up to there
-        float hv[16];
-#if LFGC_ABLATE & 2
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hv[r] = 0.5f * av[r];
-#else
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hv[r] = lfgc_snake_t<false>(av[r]);
-#endif
-        if (LAST) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_final + 32 * m + 8 * q + 4 * hh);
-                ydot = __builtin_fmaf(w4.x, hv[4 * q + 0], ydot); ydot = __builtin_fmaf(w4.y, hv[4 * q + 1], ydot);
-                ydot = __builtin_fmaf(w4.z, hv[4 * q + 2], ydot); ydot = __builtin_fmaf(w4.w, hv[4 * q + 3], ydot);
+            t0 = __builtin_fmaf(acc[2 * P], inv_scale, bq[Q & 1][I]);
+            t1 = __builtin_fmaf(acc[2 * P + 1], inv_scale, bq[Q & 1][I + 1]);
+            c0 = __builtin_amdgcn_cosf(t0);                              // cos(2 pi t)
+            if (STASH) {                                                  // the backward kernels read a = pi t
+                stash[(2 * P) * 64] = t0 * 3.14159274101257324f;
+                stash[(2 * P + 1) * 64] = t1 * 3.14159274101257324f;
+            }
+            if (LAST) tmax = lfgc_absmax3(tmax, t0, t1);
+        } else if constexpr (S == 1) {
+            c1 = __builtin_amdgcn_cosf(t1);
+            if (LAST) {       // unscaled result for the fp32 head: pi/2 as a two-term constant
+                const float e0 = __builtin_fmaf(t0, -4.371138828673793e-08f, __builtin_fmaf(c0, -0.5f, 0.5f));
+                h0 = __builtin_fmaf(t0, 1.5707963705062866f, e0);
+            } else {
+                h0 = __builtin_fmaf(t0, LFGC_ACT_C, __builtin_fmaf(c0, -LFGC_ACT_HALF, LFGC_ACT_HALF));
             }
         } else {
-#if LFGC_ABLATE & 8
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { Ohi[2 * m][t] = (_Float16)hv[t]; Olo[2 * m][t] = (_Float16)0; Ohi[2 * m + 1][t] = (_Float16)hv[8 + t]; Olo[2 * m + 1][t] = (_Float16)0; }
-#else
-            if (SPLIT) {
-                lfgc_split8(hv, Ohi[2 * m], Olo[2 * m]);
-                lfgc_split8(hv + 8, Ohi[2 * m + 1], Olo[2 * m + 1]);
+            if (LAST) {
+                const float e = __builtin_fmaf(t1, -4.371138828673793e-08f, __builtin_fmaf(c1, -0.5f, 0.5f));
+                h1 = __builtin_fmaf(t1, 1.5707963705062866f, e);
+                ydot = __builtin_fmaf(wq[Q & 1][I], h0, ydot);
+                ydot = __builtin_fmaf(wq[Q & 1][I + 1], h1, ydot);
             } else {
-                lfgc_cvt8(hv, Ohi[2 * m]);
-                lfgc_cvt8(hv + 8, Ohi[2 * m + 1]);
+                h1 = __builtin_fmaf(t1, LFGC_ACT_C, __builtin_fmaf(c1, -LFGC_ACT_HALF, LFGC_ACT_HALF));
+                const unsigned hp = lfgc_cvt_pk(h0, h1);
+                Ohi[P >> 2][P & 3] = hp;
+                if (SPLIT) Olo[P >> 2][P & 3] = lfgc_lo_pk(hp, h0, h1);
             }
-#endif
         }
+    }
+};
+
+// The gaps of one output tile: G = KS16 * (SPLIT ? 3 : 1) MFMAs accumulating into `acc` (started from 0: the bias is
+// added in the epilogue), each followed by the A-operand read of the next k-step (or of `arow_next`'s first) and by its
+// slice of the pending epilogue `ep` of accumulator `eacc` (24 slots spread over the first GA gaps; GA = 0: nothing
+// pending).  The epilogue writes fragments Ehi / Elo; when these are IN's own last two (a tile carried over from the
+// previous layer, GA = gaps of the first KS16 - 2 k-steps) they are copied into IN before k-step KS16 - 2 reads them.
+// whi / wlo hold k-step 0's operands on entry and the next tile's on exit.
+template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, class EPI>
+__device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, const float* __restrict__ arow_next,
+                                               u32x4 (&INhi)[KS16], u32x4 (&INlo)[KS16], f32x16& acc,
+                                               h16x8& whi, h16x8& wlo, EPI& ep, const f32x16& eacc,
+                                               u32x4 (&Ehi)[2], u32x4 (&Elo)[2], float& ydot, float& tmax) {
+    constexpr int MPK = SPLIT ? 3 : 1;
+    static_assert(!E_IS_IN_TAIL || GA <= (KS16 - 2) * MPK, "a carried tile must be done before the k-steps that read it");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    lfgc_static_for<KS16>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if constexpr (E_IS_IN_TAIL && ks == KS16 - 2) {
+            INhi[KS16 - 2] = Ehi[0]; INhi[KS16 - 1] = Ehi[1];
+            INlo[KS16 - 2] = Elo[0]; INlo[KS16 - 1] = Elo[1];
+        }
+        h16x8 nhi = whi, nlo = wlo;
+        lfgc_static_for<MPK>([&](auto u_c) {
+            constexpr int u = decltype(u_c)::value;
+            constexpr int g = ks * MPK + u;
+            const h16x8 bh = __builtin_bit_cast(h16x8, INhi[ks]);
+            if (SPLIT) {
+                const h16x8 bl = __builtin_bit_cast(h16x8, INlo[ks]);
+                if (u == 0) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, bh, acc, 0, 0, 0);       // small terms first
+                if (u == 1) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bl, acc, 0, 0, 0);
+                if (u == 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh, acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh, acc, 0, 0, 0);
+            }
+            const float* nsrc = (ks + 1 < KS16) ? arow + 16 * (ks + 1) : arow_next;      // one read per gap
+            if (nsrc) {
+                if (u == 0) nhi = *reinterpret_cast<const h16x8*>(nsrc);
+                if (SPLIT && u == 1) nlo = *reinterpret_cast<const h16x8*>(nsrc + 4);
+            }
+            if constexpr (GA > 0 && g < GA) {
+                constexpr int s_lo = g * 24 / GA, s_hi = (g + 1) * 24 / GA;
+                lfgc_static_for<s_hi - s_lo>([&](auto s_c) {
+                    constexpr int s = s_lo + decltype(s_c)::value;
+                    ep.template slot<s / 3, s % 3>(eacc, Ehi, Elo, ydot, tmax);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        whi = nhi; wlo = nlo;
+    });
+}
+
+// What a layer leaves for the next one to finish: the accumulator of its last output tile and that tile's constants.
+struct LfgcCarry {
+    f32x16 acc;
+    float inv_scale;
+    const float* bias;
+    float* stash;
+};
+
+// One hidden layer on a 32-sample tile.  IN = KS16 input fragments (the last two still owed by `carry` when
+// HAS_CARRY: they are produced under this layer's first MFMAs), OUT = this layer's 2*MT output fragments (all but the
+// last two; those are `out_carry`'s to produce), or with LAST the head's partial dot product in `ydot` (complete).
+template <int KS16, int MT, int S, bool STASH, bool LAST, bool SPLIT, bool HAS_CARRY>
+__device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk, u32x4 (&INhi)[KS16], u32x4 (&INlo)[KS16],
+                                                 const LfgcCarry& carry, float inv_scale, const float* __restrict__ s_bias,
+                                                 u32x4 (&OUThi)[2 * MT], u32x4 (&OUTlo)[2 * MT], LfgcCarry& out_carry,
+                                                 const float* __restrict__ s_final, float& ydot, float& tmax,
+                                                 float* __restrict__ stash, int j, int hh, int lane) {
+    constexpr int MPK = SPLIT ? 3 : 1;
+    constexpr int G = KS16 * MPK;
+    const float* s_row = s_blk + j * S + 8 * hh;              // lane half hh: bytes [32 hh, 32 hh + 32) of each 64-B k-step
+    const float* bias_l = s_bias + 4 * hh;
+    const float* wf_l = s_final + 4 * hh;
+    float* stash_l = nullptr;
+    if (STASH) { stash_l = stash + lane; asm volatile("" : "+v"(stash_l)); }
+    h16x8 whi = *reinterpret_cast<const h16x8*>(s_row);
+    h16x8 wlo = whi;
+    if (SPLIT) wlo = *reinterpret_cast<const h16x8*>(s_row + 4);
+
+    f32x16 accs[2];
+    {   // tile 0: shadows the previous layer's last tile, which produces this layer's last two input fragments
+        LfgcEpilogue<STASH, false, SPLIT> ep;
+        u32x4 ehi[2], elo[2];
+        constexpr int GA0 = HAS_CARRY ? (KS16 - 2) * MPK : 0;
+        if (HAS_CARRY) {
+            ep.inv_scale = carry.inv_scale; ep.bias = carry.bias; ep.wf = nullptr; ep.stash = carry.stash;
+            ep.begin();
+            if constexpr (GA0 == 0) {      // two k-steps in all (H <= 32): both read the owed fragments, nothing to hide under
+                lfgc_static_for<24>([&](auto s_c) {
+                    constexpr int s = decltype(s_c)::value;
+                    ep.template slot<s / 3, s % 3>(carry.acc, ehi, elo, ydot, tmax);
+                });
+                INhi[KS16 - 2] = ehi[0]; INhi[KS16 - 1] = ehi[1]; INlo[KS16 - 2] = elo[0]; INlo[KS16 - 1] = elo[1];
+            }
+        }
+        lfgc_tile_gaps<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0)>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo, accs[0], whi, wlo,
+                                                    ep, carry.acc, ehi, elo, ydot, tmax);
+    }
+    // tiles 1 .. MT-1: each shadows the tile before it
+    lfgc_static_for<MT - 1>([&](auto m_c) {
+        constexpr int m = 1 + decltype(m_c)::value;
+        LfgcEpilogue<STASH, LAST, SPLIT> ep;
+        ep.inv_scale = inv_scale; ep.bias = bias_l + 32 * (m - 1); ep.wf = wf_l + 32 * (m - 1);
+        ep.stash = STASH ? stash_l + (m - 1) * (16 * 64) : nullptr;
+        ep.begin();
+        u32x4 ehi[2], elo[2];
+        lfgc_tile_gaps<KS16, SPLIT, G, false>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr, INhi, INlo,
+                                              accs[m & 1], whi, wlo, ep, accs[(m - 1) & 1], ehi, elo, ydot, tmax);
+        if (!LAST) {
+            OUThi[2 * (m - 1)] = ehi[0]; OUThi[2 * (m - 1) + 1] = ehi[1];
+            OUTlo[2 * (m - 1)] = elo[0]; OUTlo[2 * (m - 1) + 1] = elo[1];
+        }
+    });
+    // the last tile: finished here for the head, otherwise owed to the next layer
+    if (LAST) {
+        LfgcEpilogue<STASH, true, SPLIT> ep;
+        ep.inv_scale = inv_scale; ep.bias = bias_l + 32 * (MT - 1); ep.wf = wf_l + 32 * (MT - 1);
+        ep.stash = STASH ? stash_l + (MT - 1) * (16 * 64) : nullptr;
+        u32x4 ehi[2], elo[2];
+        ep.begin();
+        lfgc_static_for<24>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            ep.template slot<s / 3, s % 3>(accs[(MT - 1) & 1], ehi, elo, ydot, tmax);
+        });
+    } else {
+        out_carry.acc = accs[(MT - 1) & 1];
+        out_carry.inv_scale = inv_scale;
+        out_carry.bias = bias_l + 32 * (MT - 1);
+        out_carry.stash = STASH ? stash_l + (MT - 1) * (16 * 64) : nullptr;
     }
 }
 
@@ -154,7 +302,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_final = smem;               // Wf (HP) | bf (4)
     float* s_scale = smem + HP + 4;      // scale[8] | 1/scale[8]
-    float* s_w = s_scale + 16;           // resident: every layer block; streamed: ring of 2 x BLKMAX
+    float* s_bias = s_scale + 16;        // b/pi of every hidden layer: LFGC_MAX_LAYERS x HP
+    float* s_w = s_bias + LFGC_MAX_LAYERS * HP;   // resident: every layer block; streamed: ring of 2 x BLKMAX
     float* s_coord = s_w + (STREAM ? 2 * BLKMAX : (BLK0 + (a.L - 1) * BLK1));
 
     const int tid = threadIdx.x;
@@ -165,12 +314,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     const int L = a.L;
     const int off_final = F_BLK0 + (L - 1) * F_BLK1;
     const int off_h = off_final + HP + 4 + K0R * (HP + 4) + (L - 1) * HP * (HP + 4);
-    const float* hblk = a.packed + off_h + 16;
+    const float* hblk = a.packed + off_h + 32 + LFGC_MAX_LAYERS * HP;
 
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_final);
         for (int i = tid; i < (HP + 4) / 4; i += NT) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
-        if (tid < 16) s_scale[tid] = a.packed[off_h + tid];
+        if (tid < 16) s_scale[tid] = a.packed[off_h + 16 + tid];       // the forward images' own scales
+        for (int i = tid; i < L * HP; i += NT) s_bias[i] = a.packed[off_h + 32 + i];
         if (!STREAM) {
             const f32x4* srcw = reinterpret_cast<const f32x4*>(hblk);
             for (int i = tid; i < (BLK0 + (L - 1) * BLK1) / 4; i += NT) reinterpret_cast<f32x4*>(s_w)[i] = srcw[i];
@@ -231,50 +381,62 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             ++step;
             return blk;
         };
+        auto stash_of = [&](int l) -> float* { return STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr; };
 
-        float ydot = 0.0f;
-        h16x8 Ahi[2 * MT], Alo[2 * MT], Bhi[2 * MT], Blo[2 * MT];
+        float ydot = 0.0f, tmax = 0.0f;
+        u32x4 Ahi[2 * MT], Alo[2 * MT], Bhi[2 * MT], Blo[2 * MT];
+        LfgcCarry ca, cb;
         {   // layer 0
-            h16x8 X0hi[KS16_0], X0lo[KS16_0];
+            u32x4 X0hi[KS16_0], X0lo[KS16_0];
 #pragma unroll
             for (int s = 0; s < KS16_0; ++s) {
-                if (SPLIT) lfgc_split8(X + 8 * s, X0hi[s], X0lo[s]);
-                else lfgc_cvt8(X + 8 * s, X0hi[s]);
+                h16x8 fh, fl;
+                if (SPLIT) lfgc_split8(X + 8 * s, fh, fl);
+                else { lfgc_cvt8(X + 8 * s, fh); fl = fh; }
+                X0hi[s] = __builtin_bit_cast(u32x4, fh); X0lo[s] = __builtin_bit_cast(u32x4, fl);
             }
             const float* blk = acquire(0);
             if (L == 1)
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT>(blk, X0hi, X0lo, s_scale[8], Ahi, Alo, s_final, ydot, stash_tile, j, hh, lane);
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT, false>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                                                                            s_final, ydot, tmax, stash_of(0), j, hh, lane);
             else
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false, SPLIT>(blk, X0hi, X0lo, s_scale[8], Ahi, Alo, s_final, ydot, stash_tile, j, hh, lane);
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false, SPLIT, false>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                                                                             s_final, ydot, tmax, stash_of(0), j, hh, lane);
         }
         // hidden layers 1 .. L-2 in ping-pong pairs, then the last one with the head folded in
         {
             int l = 1;
             for (; l + 2 < L; l += 2) {
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
-                                                              STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane);
                 blk = acquire(l + 1);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT>(blk, Bhi, Blo, s_scale[9 + l], Ahi, Alo, s_final, ydot,
-                                                              STASH ? stash_tile + (long long)(l + 1) * (64 * 16 * MT) : nullptr, j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true>(blk, Bhi, Blo, cb, s_scale[9 + l], s_bias + (l + 1) * HP, Ahi, Alo, ca,
+                                                                            s_final, ydot, tmax, stash_of(l + 1), j, hh, lane);
             }
             if (l + 1 < L) {       // one more non-final layer: A -> B, final consumes B
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
-                                                              STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane);
                 ++l;
                 blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT>(blk, Bhi, Blo, s_scale[8 + l], Ahi, Alo, s_final, ydot,
-                                                             STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true>(blk, Bhi, Blo, cb, s_scale[8 + l], s_bias + l * HP, Ahi, Alo, ca,
+                                                                           s_final, ydot, tmax, stash_of(l), j, hh, lane);
             } else if (l < L) {    // final layer consumes A
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT>(blk, Ahi, Alo, s_scale[8 + l], Bhi, Blo, s_final, ydot,
-                                                             STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr, j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                                                                           s_final, ydot, tmax, stash_of(l), j, hh, lane);
             }
         }
 
         float y = ydot + __shfl_xor(ydot, 32);
         y += s_final[HP];
+        // range screen (header comment): an f16 overflow anywhere upstream has made y NaN; the last layer's
+        // pre-activations are checked explicitly.  A sample the fast arithmetic cannot do is reported, never returned
+        // as a finite wrong number.
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        if (!(tmax <= LFGC_TURNS_MAX)) y = __builtin_nanf("");
+        if (a.status && valid && !(__builtin_fabsf(y) < __builtin_inff())) *a.status = 1;
         if (a.clamp) y = fminf(fmaxf(y, -1.0f), 1.0f);
         if (valid && hh == 0) a.out[n] = y;
     }
@@ -283,12 +445,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
 template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT>
 static int lfgc_launch_fwd16_cfg(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
     auto kern = lfgc_fwd16_kernel<CH, MT, NF, WAVES, STREAM, STASH, SPLIT>;
-    static int lds_limit_set = 0;          // per instantiation; raised once (also keeps launches graph-capturable)
-    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set) {
+    // the >64 KB dynamic-LDS attribute is per device: raised once per (instantiation, device); one-time, so launches
+    // stay graph-capturable
+    static int lds_limit_set[LFGC_MAX_DEVICES] = {0};
+    const int dev = lfgc_current_device();
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_limit_set[dev]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
-        lds_limit_set = lds_bytes;
+        lds_limit_set[dev] = lds_bytes;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), lds_bytes, stream, a);
     LFGC_HIP_CHECK_LAUNCH();

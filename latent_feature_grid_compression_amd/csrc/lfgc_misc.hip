@@ -179,9 +179,23 @@ struct PackArgs {
     LfgcPlan plan;
 };
 
-// Per-layer power-of-two scale for the f16-split blocks: 2^S with max|W| * 2^S in [2^13, 2^14), so that the hi
+// Per-layer power-of-two scales for the f16-split images: 2^S with max|w| * 2^S in [2^13, 2^14), so that the hi
 // halves stay far below the f16 maximum and the lo halves (<= 2^-11 of the hi) stay normal for every weight within
-// 2^-16 of the largest.  One block per hidden layer.
+// 2^-16 of the largest.  Two sets: the transposed images of the backward chain hold W itself, the forward images hold
+// W / pi (layer 0) or W / (pi LFGC_ACT_SCALE) (lfgc_forward16.h: pre-activations in turns of pi, inputs of layers >= 1
+// scaled).  One block per hidden layer.
+__device__ __forceinline__ double lfgc_fwd_image_divisor(int l) {
+    return l == 0 ? 3.14159265358979323846 : 3.14159265358979323846 * LFGC_ACT_SCALE;
+}
+
+__device__ __forceinline__ int lfgc_pow2_exponent_for(float m) {
+    int e = 0;
+    if (m > 0.0f && m < INFINITY) { (void)frexpf(m, &e); e = 14 - e; }    // m = f * 2^e', f in [0.5,1) -> m * 2^(14-e') in [2^13, 2^14)
+    if (e > 60) e = 60;
+    if (e < -60) e = -60;
+    return e;
+}
+
 __global__ __launch_bounds__(1024) void pack_scale_kernel(const PackArgs a) {
     const LfgcPlan& p = a.plan;
     const int l = blockIdx.x;
@@ -202,12 +216,12 @@ __global__ __launch_bounds__(1024) void pack_scale_kernel(const PackArgs a) {
     if (threadIdx.x == 0) {
         m = 0.0f;
         for (int k = 0; k < 16; ++k) m = fmaxf(m, s[k]);
-        int e = 0;
-        if (m > 0.0f && m < INFINITY) { (void)frexpf(m, &e); e = 14 - e; }    // m = f * 2^e', f in [0.5,1) -> m * 2^(14-e') in [2^13, 2^14)
-        if (e > 60) e = 60;
-        if (e < -60) e = -60;
+        const int e = lfgc_pow2_exponent_for(m);
         a.packed[p.off_h + l] = ldexpf(1.0f, e);
         a.packed[p.off_h + 8 + l] = ldexpf(1.0f, -e);
+        const int ef = lfgc_pow2_exponent_for((float)((double)m / lfgc_fwd_image_divisor(l)));
+        a.packed[p.off_h + 16 + l] = ldexpf(1.0f, ef);
+        a.packed[p.off_h + 24 + l] = ldexpf(1.0f, -ef);
     }
 }
 
@@ -255,8 +269,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
             const int oo = o % p.tblk1;
             const int ki = oo / p.ST, ho = oo % p.ST;
             if (ki < p.H && ho < p.H) v = a.w[l][ho * p.H + ki];
-        } else if (idx < p.off_hblk) {
+        } else if (idx < p.off_hbias) {
             continue;                                         // scales: written by pack_scale_kernel
+        } else if (idx < p.off_hblk) {                        // b / pi of the hidden layers, [layer][row]
+            const int l = (idx - p.off_hbias) / p.HP, r = (idx - p.off_hbias) % p.HP;
+            if (l < p.L && r < p.H) v = (float)((double)a.b[l][r] / 3.14159265358979323846);
         } else if (idx >= p.off_ht) {                         // f16-split transposed images: [row = k_in][k = h_out]
             const int o = idx - p.off_ht;
             const int l = o < p.tblk0 ? 0 : 1 + (o - p.tblk0) / p.tblk1;
@@ -291,7 +308,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
             const int SH = l == 0 ? p.SH0 : p.SH1;
             const int K = l == 0 ? p.K0P16 : p.HP;
             const int Kin = l == 0 ? (p.E + p.C) : p.H;
-            const float scale = a.packed[p.off_h + l];
+            // W / pi [/ LFGC_ACT_SCALE] in fp64, then the power-of-two scale, then the split: the image carries the
+            // quotient to the 22-24 bits of the split itself
+            const double scale = (double)a.packed[p.off_h + 16 + l] / lfgc_fwd_image_divisor(l);
             if (oo < p.HP * SH) {
                 const int row = oo / SH, q = oo % SH;
                 unsigned bits = 0;
@@ -302,9 +321,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
                     for (int u = 0; u < 2; ++u) {
                         const int src = lfgc_h16_src_col(p, l, b, hp, 2 * pair + u);
                         if (src >= 0) {
-                            const float w = a.w[l][row * Kin + src] * scale;
+                            const double w = (double)a.w[l][row * Kin + src] * scale;
                             const _Float16 hi = (_Float16)w;
-                            const _Float16 lo = (_Float16)(w - (float)hi);
+                            const _Float16 lo = (_Float16)(w - (double)hi);
                             const _Float16 x = part ? lo : hi;
                             hv[u] = *reinterpret_cast<const unsigned short*>(&x);
                         }
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
                 v = __uint_as_float(bits);
             } else {
                 const int r = oo - p.HP * SH;
-                if (r < p.H) v = a.b[l][r] * scale;
+                v = 0.0f;                                     // (bias slot of the block: unused, the biases live at off_hbias)
             }
         }
         a.packed[idx] = v;

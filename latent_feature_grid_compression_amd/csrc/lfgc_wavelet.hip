@@ -600,26 +600,28 @@ int launch_idwt(IdwtArgs a, bool drop, const float* taps, hipStream_t stream) {
     const dim3 blocks((unsigned)ptiles, (unsigned)((n0 + 1) / 2), (unsigned)a.C);
     const int lds = (512 + 3 * a.len * kRec) * 4;
     if ((long long)a.d0 * a.d1 * a.d2 > 0x7fffffffLL / 8 || (long long)a.t0 * a.t1 * a.t2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
-    static int lim[4] = {0, 0, 0, 0};
+    static int lim[4][LFGC_MAX_DEVICES] = {{0}};       // per (kernel, device)
+    const int dev_lim = lfgc_current_device();
     const int ki = (a.len + 255) / 256;
     if (taps && ki <= 3) {                                   // separable filter: sliding window along z
         a.zchunk = n0 < 6 ? n0 : 5;
         const dim3 sblocks((unsigned)ptiles, (unsigned)((n0 + a.zchunk - 1) / a.zchunk), (unsigned)a.C);
         const int slds = 2 * a.len * kRec * 4;
-        static int slim[6] = {0, 0, 0, 0, 0, 0};
+        static int slim[6][LFGC_MAX_DEVICES] = {{0}};       // per (kernel, device)
+    const int dev_slim = lfgc_current_device();
         if (drop) {
-            if (ki == 1) return launch_tiled(idwt_slide_kernel<true, 1>, &slim[0], a, sblocks, slds, stream);
-            if (ki == 2) return launch_tiled(idwt_slide_kernel<true, 2>, &slim[1], a, sblocks, slds, stream);
-            return launch_tiled(idwt_slide_kernel<true, 3>, &slim[2], a, sblocks, slds, stream);
+            if (ki == 1) return launch_tiled(idwt_slide_kernel<true, 1>, &slim[0][dev_slim], a, sblocks, slds, stream);
+            if (ki == 2) return launch_tiled(idwt_slide_kernel<true, 2>, &slim[1][dev_slim], a, sblocks, slds, stream);
+            return launch_tiled(idwt_slide_kernel<true, 3>, &slim[2][dev_slim], a, sblocks, slds, stream);
         }
-        if (ki == 1) return launch_tiled(idwt_slide_kernel<false, 1>, &slim[3], a, sblocks, slds, stream);
-        if (ki == 2) return launch_tiled(idwt_slide_kernel<false, 2>, &slim[4], a, sblocks, slds, stream);
-        return launch_tiled(idwt_slide_kernel<false, 3>, &slim[5], a, sblocks, slds, stream);
+        if (ki == 1) return launch_tiled(idwt_slide_kernel<false, 1>, &slim[3][dev_slim], a, sblocks, slds, stream);
+        if (ki == 2) return launch_tiled(idwt_slide_kernel<false, 2>, &slim[4][dev_slim], a, sblocks, slds, stream);
+        return launch_tiled(idwt_slide_kernel<false, 3>, &slim[5][dev_slim], a, sblocks, slds, stream);
     }
-    if (taps) return drop ? launch_tiled(idwt_level_kernel<true, true>, &lim[3], a, blocks, lds, stream)
-                          : launch_tiled(idwt_level_kernel<false, true>, &lim[2], a, blocks, lds, stream);
-    return drop ? launch_tiled(idwt_level_kernel<true, false>, &lim[1], a, blocks, lds, stream)
-                : launch_tiled(idwt_level_kernel<false, false>, &lim[0], a, blocks, lds, stream);
+    if (taps) return drop ? launch_tiled(idwt_level_kernel<true, true>, &lim[3][dev_lim], a, blocks, lds, stream)
+                          : launch_tiled(idwt_level_kernel<false, true>, &lim[2][dev_lim], a, blocks, lds, stream);
+    return drop ? launch_tiled(idwt_level_kernel<true, false>, &lim[1][dev_lim], a, blocks, lds, stream)
+                : launch_tiled(idwt_level_kernel<false, false>, &lim[0][dev_lim], a, blocks, lds, stream);
 }
 
 int launch_analysis(AnalysisArgs a, bool drop, const float* taps, hipStream_t stream) {
@@ -631,11 +633,12 @@ int launch_analysis(AnalysisArgs a, bool drop, const float* taps, hipStream_t st
     const dim3 blocks((unsigned)ptiles, (unsigned)((a.d0 + 1) / 2), (unsigned)a.C);
     const int lds = (512 + 6 * a.len) * 4;
     if ((long long)a.n0 * a.n1 * a.n2 > 0x7fffffffLL) return LFGC_E_UNSUPPORTED;
-    static int lim[4] = {0, 0, 0, 0};
-    if (taps) return drop ? launch_tiled(analysis_kernel<true, true>, &lim[3], a, blocks, lds, stream)
-                          : launch_tiled(analysis_kernel<false, true>, &lim[2], a, blocks, lds, stream);
-    return drop ? launch_tiled(analysis_kernel<true, false>, &lim[1], a, blocks, lds, stream)
-                : launch_tiled(analysis_kernel<false, false>, &lim[0], a, blocks, lds, stream);
+    static int lim[4][LFGC_MAX_DEVICES] = {{0}};       // per (kernel, device)
+    const int dev_lim = lfgc_current_device();
+    if (taps) return drop ? launch_tiled(analysis_kernel<true, true>, &lim[3][dev_lim], a, blocks, lds, stream)
+                          : launch_tiled(analysis_kernel<false, true>, &lim[2][dev_lim], a, blocks, lds, stream);
+    return drop ? launch_tiled(analysis_kernel<true, false>, &lim[1][dev_lim], a, blocks, lds, stream)
+                : launch_tiled(analysis_kernel<false, false>, &lim[0][dev_lim], a, blocks, lds, stream);
 }
 
 }  // namespace

@@ -536,8 +536,10 @@ def _positions_struct(pos: Optional[torch.Tensor], lattice=None) -> Tuple[Positi
 
 def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos: Optional[torch.Tensor] = None,
                 lattice=None, clamp: bool = False, want_stash: bool = False, out: Optional[torch.Tensor] = None,
-                precision: str = 'f16x2'):
-    """lfgc_forward_f32.  pos (N,3) or lattice=(res, x_begin, x_end, tile).  Returns (y (N,), stash or None)."""
+                precision: str = 'f16x2', range_fallback: bool = True, return_status: bool = False):
+    """lfgc_forward_f32.  pos (N,3) or lattice=(res, x_begin, x_end, tile).  Returns (y (N,), stash or None)
+    [+ the device status word with return_status].  range_fallback=False returns out-of-range samples of the f16
+    builds as NaN instead of redoing the pass on the exact build (diagnostics)."""
     lib = _lib.load()
     _require_hip(grid_cl, packed, pos)
     if pos is not None:
@@ -553,9 +555,15 @@ def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos:
     stash = None
     if want_stash:
         stash = torch.empty(int(lib.lfgc_stash_bytes(ctypes.byref(desc), n)) // 4, dtype=torch.float32, device=grid_cl.device)
+    # range status word of the f16 builds: the library clears it, the kernel sets it, and the exact-fp32 redo the library
+    # enqueues behind the kernel is predicated on it -- all in stream order, nothing is read back here
+    status = torch.empty(1, dtype=torch.int32, device=grid_cl.device) if (range_fallback and precision != 'fp32') else None
     check(lib.lfgc_forward_f32(ctypes.byref(desc), ctypes.byref(ps), grid_cl.data_ptr(), D, H, W, packed.data_ptr(),
                                _lib.PRECISION[precision], int(clamp), out.data_ptr(),
-                               stash.data_ptr() if stash is not None else None, _stream(grid_cl)), 'lfgc_forward_f32')
+                               stash.data_ptr() if stash is not None else None,
+                               status.data_ptr() if status is not None else None, _stream(grid_cl)), 'lfgc_forward_f32')
+    if return_status:
+        return out, stash, status
     return out, stash
 
 

@@ -55,7 +55,7 @@ def test_pure_host_entry_points(built_lib):
     HP, K0P, K0R, L = 128, 48, 64, 4
     fwd = HP * (K0P + 4) + HP + (L - 1) * (HP * (HP + 4) + HP) + HP + 4
     tr = K0R * (HP + 4) + (L - 1) * HP * (HP + 4)
-    h16 = 16 + HP * (48 + 4) + HP + (L - 1) * (HP * (HP + 4) + HP)        # scales + f16-split blocks (K0P16 = 48)
+    h16 = 32 + 8 * HP + HP * (48 + 4) + HP + (L - 1) * (HP * (HP + 4) + HP)   # 2 x 16 scales + biases / pi + f16-split blocks (K0P16 = 48)
     assert lib.lfgc_packed_bytes(ctypes.byref(ok)) == 4 * (fwd + tr + h16 + tr)     # + f16-split transposed images
     # stash: whole workgroup batches of 8 x 32 samples, 64 lanes x (KS0 + L*16*MT) floats per tile
     assert lib.lfgc_stash_bytes(ctypes.byref(ok), 1) == 4 * 8 * 64 * (24 + 4 * 64)
@@ -66,7 +66,7 @@ def test_pure_host_entry_points(built_lib):
     # NULL / shape errors are reported before anything is launched
     assert lib.lfgc_idwt_level_f32(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, None) == -1
     assert lib.lfgc_penalty_sums_f32(None, 0, None, None) == -1 and lib.lfgc_drop_apply_f32(None, None, 0.0, None, 1, 1, None) == -1
-    assert lib.lfgc_forward_f32(ctypes.byref(ok), None, None, 1, 1, 1, None, 0, 0, None, None, None) == -1
+    assert lib.lfgc_forward_f32(ctypes.byref(ok), None, None, 1, 1, 1, None, 0, 0, None, None, None, None) == -1
     assert lib.lfgc_gt_interp_f32(None, None, None, None, None, 0, 1, 1, 1, None, None) == -1
 
 
