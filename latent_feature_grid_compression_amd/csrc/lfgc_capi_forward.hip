@@ -12,7 +12,15 @@ int lfgc_fwd16_dispatch_ch32(int MT, const LfgcFwdArgs& a, int lds_bytes, int gr
 
 namespace {
 int num_cus() { return lfgc_num_cus(); }
+#ifdef LFGC_STAMPS
+unsigned long long* g_stamps = nullptr;
+#endif
 }  // namespace
+
+#ifdef LFGC_STAMPS
+// Diagnostics builds only (tools/phase_stamps.py): device buffer of 16 counters per wave slot (grid x 8 waves).
+extern "C" void lfgc_debug_set_stamp_buffer(void* p) { g_stamps = reinterpret_cast<unsigned long long*>(p); }
+#endif
 
 // Validates `positions` and fills the position part of the kernel arguments; returns the sample count
 // through *n_out.
@@ -46,6 +54,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     if (!desc || !positions || !grid_cl || !packed || !out) return LFGC_E_NULL;
     if (!lfgc_mlp_supported(desc)) return LFGC_E_UNSUPPORTED;
     if (D < 1 || H < 1 || W < 1) return LFGC_E_SHAPE;
+    if ((long long)D * H * W * lfgc_roundup(desc->grid_channels, 8) >= (1LL << 30)) return LFGC_E_UNSUPPORTED;   // 32-bit byte offsets
     if (precision != LFGC_PRECISION_F32 && precision != LFGC_PRECISION_F16X2 && precision != LFGC_PRECISION_F16) return LFGC_E_UNSUPPORTED;
     if ((((uintptr_t)grid_cl) | ((uintptr_t)packed)) & 15) return LFGC_E_ALIGN;
     const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
@@ -62,7 +71,10 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     // whole 128-sample groups either way (lfgc_stash_bytes), so both builds write the same format.
     const bool h16 = precision != LFGC_PRECISION_F32;
     a.single = precision == LFGC_PRECISION_F16 ? 1 : 0;
-    a.status = nullptr; a.redo_if = nullptr;
+    a.status = nullptr; a.redo_if = nullptr; a.stamps = nullptr;
+#ifdef LFGC_STAMPS
+    a.stamps = g_stamps;
+#endif
     const int all_blocks = h16 ? p.blkh0 + (p.L - 1) * p.blkh1 : p.off_final;
     const int max_block = h16 ? (p.blkh0 > p.blkh1 ? p.blkh0 : p.blkh1) : (p.blk0 > p.blk1 ? p.blk0 : p.blk1);
     const int fixed = p.HP + 4 + (h16 ? 16 + LFGC_MAX_LAYERS * p.HP : 0);   // [Wf | bf] (+ per-layer scales + resident biases)

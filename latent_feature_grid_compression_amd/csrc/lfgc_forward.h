@@ -46,6 +46,7 @@ struct LfgcFwdArgs {
     int single;                // f16 builds: 1 = single product W_hi.h_hi (LFGC_PRECISION_F16), 0 = hi/lo split
     int* status;               // f16 builds: set to 1 when a sample left the range of the fast arithmetic (or nullptr)
     const int* redo_if;        // exact build: run only if *redo_if != 0 (nullptr: always) -- the range fallback
+    unsigned long long* stamps;   // diagnostics builds (-DLFGC_STAMPS, tools/phase_stamps.py): per-wave cycle totals per phase
 };
 
 // Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile
@@ -75,120 +76,153 @@ __device__ __forceinline__ float lfgc_lattice_coord(int v, int res, int tile, fl
     return __fmul_rn(scale, nrm);
 }
 
-// Positions, trilinear gather and Fourier embedding for the lane's sample: X[0..CH/2) = interpolated grid channels
-// [hh*CH/2, (hh+1)*CH/2), X[CH/2 .. CH/2 + EP/2) = this lane half's share of [p | sin f_k p | cos f_k p | 0 pad].
+// Positions, trilinear gather and Fourier embedding for the lane's sample, in two phases so that the gather's 8 x CH/8
+// 16-byte loads are in flight while the caller does something else (the f16 build puts its layer-0 barrier there):
+//   issue():  position, ATen's unnormalise / floor / corner weights (zero padding = zero weight), the 8 corner rows
+//             requested into registers;
+//   finish(): X[0..CH/2) = interpolated grid channels [hh*CH/2, (hh+1)*CH/2), X[CH/2 .. CH/2 + EP/2) = this lane half's
+//             share of [p | sin f_k p | cos f_k p | 0 pad].
+// Corner offsets are 32-bit (the host entry refuses grids of 4 GiB or more); all conditions are evaluated as masks,
+// not short-circuit branches.
 template <int CH, int NF>
-__device__ __forceinline__ void lfgc_sample_inputs(const LfgcFwdArgs& a, long long nc, long long N, const float* s_coord,
-                                               int hh, float (&B0)[CH / 2 + ((3 + 6 * NF + 7) / 8 * 8) / 2]) {
-    constexpr int E = 3 + 6 * NF;
-    constexpr int EP = (E + 7) / 8 * 8;
-    constexpr int CHH = CH / 2;
-    constexpr int EPH = EP / 2;
-    // ---- positions ---------------------------------------------------------------------------
+struct LfgcSampler {
+    static constexpr int E = 3 + 6 * NF;
+    static constexpr int EP = (E + 7) / 8 * 8;
+    static constexpr int CHH = CH / 2;
+    static constexpr int EPH = EP / 2;
     float p0, p1, p2;
-    if (a.pos) {
-        const float* pp = a.pos + 3 * nc;
-        p0 = pp[0]; p1 = pp[1]; p2 = pp[2];
-    } else {
-        int vx, vy, vz;
-        if (N <= 0xffffffffLL) {                          // 32-bit index arithmetic (any slab up to 1625^3)
-            const unsigned plane = (unsigned)a.res1 * (unsigned)a.res2;
-            const unsigned un = (unsigned)nc;
-            const unsigned qx = un / plane, rem = un - qx * plane;
-            const unsigned qy = rem / (unsigned)a.res2;
-            vx = a.x_begin + (int)qx; vy = (int)qy; vz = (int)(rem - qy * (unsigned)a.res2);
-        } else {
-            const long long plane = (long long)a.res1 * a.res2;
-            vx = a.x_begin + (int)(nc / plane);
-            const long long rem = nc % plane;
-            vy = (int)(rem / a.res2); vz = (int)(rem % a.res2);
-        }
-        if (a.coord_table) {
-            p0 = s_coord[vx]; p1 = s_coord[a.res0 + vy]; p2 = s_coord[a.res0 + a.res1 + vz];
-        } else {
-            p0 = lfgc_lattice_coord(vx, a.res0, a.tile, a.scale0);
-            p1 = lfgc_lattice_coord(vy, a.res1, a.tile, a.scale1);
-            p2 = lfgc_lattice_coord(vz, a.res2, a.tile, a.scale2);
-        }
-    }
+    float w[8];
+    f32x4 v[8][CHH / 4];
 
-    // ---- trilinear gather: lane (j, hh) interpolates channels [hh*CHH, (hh+1)*CHH) -------------
-    {
+    __device__ __forceinline__ void issue(const LfgcFwdArgs& a, long long nc, long long N, const float* s_coord, int hh) {
+        // ---- positions ---------------------------------------------------------------------------
+        if (a.pos) {
+            const float* pp = a.pos + 3 * nc;
+            p0 = pp[0]; p1 = pp[1]; p2 = pp[2];
+        } else {
+            int vx, vy, vz;
+            if (N <= 0xffffffffLL) {                          // 32-bit index arithmetic (any slab up to 1625^3)
+                const unsigned plane = (unsigned)a.res1 * (unsigned)a.res2;
+                const unsigned un = (unsigned)nc;
+                const unsigned qx = un / plane, rem = un - qx * plane;
+                const unsigned qy = rem / (unsigned)a.res2;
+                vx = a.x_begin + (int)qx; vy = (int)qy; vz = (int)(rem - qy * (unsigned)a.res2);
+            } else {
+                const long long plane = (long long)a.res1 * a.res2;
+                vx = a.x_begin + (int)(nc / plane);
+                const long long rem = nc % plane;
+                vy = (int)(rem / a.res2); vz = (int)(rem % a.res2);
+            }
+            if (a.coord_table) {
+                p0 = s_coord[vx]; p1 = s_coord[a.res0 + vy]; p2 = s_coord[a.res0 + a.res1 + vz];
+            } else {
+                p0 = lfgc_lattice_coord(vx, a.res0, a.tile, a.scale0);
+                p1 = lfgc_lattice_coord(vy, a.res1, a.tile, a.scale1);
+                p2 = lfgc_lattice_coord(vz, a.res2, a.tile, a.scale2);
+            }
+        }
+        // ---- trilinear gather: lane (j, hh) interpolates channels [hh*CHH, (hh+1)*CHH) -------------
         // grid_sampler_unnormalize, align_corners=False: ((p + 1) * size - 1) / 2   (ATen GridSampler.h)
-        const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p0, 1.0f), (float)a.W), 1.0f), 2.0f);
-        const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p1, 1.0f), (float)a.H), 1.0f), 2.0f);
-        const float iz = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(p2, 1.0f), (float)a.D), 1.0f), 2.0f);
+        const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p0, 1.0f), (float)a.W), 1.0f), 0.5f);
+        const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p1, 1.0f), (float)a.H), 1.0f), 0.5f);
+        const float iz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p2, 1.0f), (float)a.D), 1.0f), 0.5f);
         const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
-        // clamp before the int conversion so absurd positions stay defined (they get weight 0 anyway)
+        // clamped to [-2, size] before the conversion: absurd / NaN positions stay defined, and every corner of such a
+        // sample is then out of bounds (weight 0) by the index test alone
         const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)a.W);
         const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)a.H);
         const int z0 = (int)fminf(fmaxf(fz0, -2.0f), (float)a.D);
-        const float wx1 = __fsub_rn(ix, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
-        const float wy1 = __fsub_rn(iy, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
-        const float wz1 = __fsub_rn(iz, fz0), wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
-        const bool in_range = (fx0 >= -1.0f) && (fx0 < (float)a.W) && (fy0 >= -1.0f) && (fy0 < (float)a.H) &&
-                              (fz0 >= -1.0f) && (fz0 < (float)a.D);
+        float wx[2], wy[2], wz[2];
+        wx[1] = __fsub_rn(ix, fx0); wx[0] = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+        wy[1] = __fsub_rn(iy, fy0); wy[0] = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+        wz[1] = __fsub_rn(iz, fz0); wz[0] = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
+        unsigned ox[2], oy[2], oz[2];                   // BYTE offsets (32-bit: one SGPR base + one VGPR offset per load)
+        const unsigned cell = 4u * (unsigned)a.Cs, row = (unsigned)a.W * cell, plane = (unsigned)a.H * row;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {          // out-of-bounds corner = zero weight on that axis; its (clamped) row is still read
+            wx[d] = ((unsigned)(x0 + d) < (unsigned)a.W) ? wx[d] : 0.0f;
+            wy[d] = ((unsigned)(y0 + d) < (unsigned)a.H) ? wy[d] : 0.0f;
+            wz[d] = ((unsigned)(z0 + d) < (unsigned)a.D) ? wz[d] : 0.0f;
+            ox[d] = (unsigned)min(max(x0 + d, 0), a.W - 1) * cell + (unsigned)(hh * CHH * 4);
+            oy[d] = (unsigned)min(max(y0 + d, 0), a.H - 1) * row;
+            oz[d] = (unsigned)min(max(z0 + d, 0), a.D - 1) * plane;
+        }
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int dz = corner >> 2, dy = (corner >> 1) & 1, dx = corner & 1;   // ATen order: tnw, tne, tsw, tse, bnw, ...
+            w[corner] = __fmul_rn(__fmul_rn(wx[dx], wy[dy]), wz[dz]);
+#if !(LFGC_ABLATE & 1)
+            const float* gp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.grid) + (oz[dz] + oy[dy] + ox[dx]));
+#pragma unroll
+            for (int c4 = 0; c4 < CHH / 4; ++c4) v[corner][c4] = *reinterpret_cast<const f32x4*>(gp + 4 * c4);
+#else
+#pragma unroll
+            for (int c4 = 0; c4 < CHH / 4; ++c4) v[corner][c4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#endif
+        }
+    }
+
+    __device__ __forceinline__ void finish(int hh, float (&B0)[CHH + EPH]) {
+        // ---- scalar inputs [p | sin f_k p | cos f_k p]: every lane evaluates all, keeps its half -----
+        {
+            float e[EP];
+            e[0] = p0; e[1] = p1; e[2] = p2;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const float f = lfgc_freq(k);
+                const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f);
+                bad |= lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2);
+                float s, c;
+                lfgc_sincosf_t<false>(a0, s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
+                lfgc_sincosf_t<false>(a1, s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
+                lfgc_sincosf_t<false>(a2, s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
+            }
+            if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    const float f = lfgc_freq(k);
+                    float s, c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p0, f), s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p1, f), s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p2, f), s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
+                }
+            }
+#pragma unroll
+            for (int t = E; t < EP; ++t) e[t] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < EPH; ++t) {
+                float lo = e[t], hi = e[EPH + t];
+                asm volatile("" : "+v"(lo), "+v"(hi));     // keep both in VGPRs: a select of two array slots would go to scratch
+                B0[CHH + t] = hh ? hi : lo;
+            }
+        }
+        // ---- the 8 corner rows, accumulated in ATen's corner order -----------------------------------
         float feat[CHH];
 #pragma unroll
         for (int c = 0; c < CHH; ++c) feat[c] = 0.0f;
-        const float* gbase = a.grid + hh * CHH;
 #pragma unroll
-        for (int corner = 0; corner < ((LFGC_ABLATE & 1) ? 0 : 8); ++corner) {
-            const int dz = corner >> 2, dy = (corner >> 1) & 1, dx = corner & 1;   // ATen order: tnw, tne, tsw, tse, bnw, ...
-            const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
-            const bool ok = in_range && xi >= 0 && xi < a.W && yi >= 0 && yi < a.H && zi >= 0 && zi < a.D;
-            float w = __fmul_rn(__fmul_rn(dx ? wx1 : wx0, dy ? wy1 : wy0), dz ? wz1 : wz0);
-            w = ok ? w : 0.0f;
-            const int xc = min(max(xi, 0), a.W - 1), yc = min(max(yi, 0), a.H - 1), zc = min(max(zi, 0), a.D - 1);
-            const float* gp = gbase + ((long long)(zc * a.H + yc) * a.W + xc) * a.Cs;
+        for (int corner = 0; corner < 8; ++corner) {
 #pragma unroll
             for (int c4 = 0; c4 < CHH / 4; ++c4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(gp + 4 * c4);
-                feat[4 * c4 + 0] = __builtin_fmaf(v.x, w, feat[4 * c4 + 0]);
-                feat[4 * c4 + 1] = __builtin_fmaf(v.y, w, feat[4 * c4 + 1]);
-                feat[4 * c4 + 2] = __builtin_fmaf(v.z, w, feat[4 * c4 + 2]);
-                feat[4 * c4 + 3] = __builtin_fmaf(v.w, w, feat[4 * c4 + 3]);
+                const f32x4 q = v[corner][c4];
+                feat[4 * c4 + 0] = __builtin_fmaf(q.x, w[corner], feat[4 * c4 + 0]);
+                feat[4 * c4 + 1] = __builtin_fmaf(q.y, w[corner], feat[4 * c4 + 1]);
+                feat[4 * c4 + 2] = __builtin_fmaf(q.z, w[corner], feat[4 * c4 + 2]);
+                feat[4 * c4 + 3] = __builtin_fmaf(q.w, w[corner], feat[4 * c4 + 3]);
             }
         }
 #pragma unroll
         for (int c = 0; c < CHH; ++c) B0[c] = feat[c];
     }
+};
 
-    // ---- scalar inputs [p | sin f_k p | cos f_k p]: every lane evaluates all, keeps its half -----
-    {
-        float e[EP];
-        e[0] = p0; e[1] = p1; e[2] = p2;
-        bool bad = false;
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            const float f = lfgc_freq(k);
-            const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f);
-            bad |= lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2);
-            float s, c;
-            lfgc_sincosf_t<false>(a0, s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
-            lfgc_sincosf_t<false>(a1, s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
-            lfgc_sincosf_t<false>(a2, s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
-        }
-        if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
-#pragma unroll
-            for (int k = 0; k < NF; ++k) {
-                const float f = lfgc_freq(k);
-                float s, c;
-                lfgc_sincosf_t<true>(__fmul_rn(p0, f), s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
-                lfgc_sincosf_t<true>(__fmul_rn(p1, f), s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
-                lfgc_sincosf_t<true>(__fmul_rn(p2, f), s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
-            }
-        }
-#pragma unroll
-        for (int t = E; t < EP; ++t) e[t] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < EPH; ++t) {
-            float lo = e[t], hi = e[EPH + t];
-            asm volatile("" : "+v"(lo), "+v"(hi));     // keep both in VGPRs: a select of two array slots would go to scratch
-            B0[CHH + t] = hh ? hi : lo;
-        }
-    }
-
+template <int CH, int NF>
+__device__ __forceinline__ void lfgc_sample_inputs(const LfgcFwdArgs& a, long long nc, long long N, const float* s_coord,
+                                               int hh, float (&B0)[CH / 2 + ((3 + 6 * NF + 7) / 8 * 8) / 2]) {
+    LfgcSampler<CH, NF> sm;
+    sm.issue(a, nc, N, s_coord, hh);
+    sm.finish(hh, B0);
 }
 
 // One hidden layer on a 32-sample tile held in registers.

@@ -58,9 +58,9 @@ __device__ __forceinline__ unsigned lfgc_cvt_pk(float x0, float x1) {
 // lo = rne_f16(x - f32(hi)) of a pair: ONE mixed-precision FMA per value that reads the f16 half in place and writes
 // its f16 result into the destination half (hi * -1 + x is exact in fp32, so the only rounding is the final one)
 __device__ __forceinline__ unsigned lfgc_lo_pk(unsigned h, float x0, float x1) {
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
-    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+    unsigned l;        // one statement: between two asm statements hipcc puts an s_nop (an issue slot per pair)
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(l) : "v"(h), "v"(x0), "v"(x1));
     return l;
 }
 
@@ -279,6 +279,14 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
     }
 }
 
+// Diagnostics (-DLFGC_STAMPS): cycle stamps between the phases of a tile, summed per wave.  In the shipped build no
+// stamp executes.
+#ifdef LFGC_STAMPS
+#define LFGC_STAMP(k) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); st_acc[k] += now__ - st_last; st_last = now__; } while (0)
+#else
+#define LFGC_STAMP(k) do { } while (0)
+#endif
+
 template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT>
 __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwdArgs a) {
     constexpr int E = 3 + 6 * NF;
@@ -338,6 +346,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     }
     __syncthreads();
     unsigned step = 0;
+#ifdef LFGC_STAMPS
+    unsigned long long st_acc[16] = {0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const long long N = a.n;
     for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
@@ -345,33 +358,27 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
         const long long n = tile_idx * LFGC_TILE_SAMPLES + j;
         const bool valid = n < N;
         const long long nc = valid ? n : (N - 1);
+        LFGC_STAMP(0);            // loop overhead / previous tail
 
-        float X[8 * KS16_0];
-        {
-            float B0[KS0];
-            lfgc_sample_inputs<CH, NF>(a, nc, N, s_coord, hh, B0);
-#pragma unroll
-            for (int s = 0; s < KS0; ++s) X[s] = B0[s];
-#pragma unroll
-            for (int s = KS0; s < 8 * KS16_0; ++s) X[s] = 0.0f;
-        }
-
-        float* stash_tile = nullptr;
-        if (STASH) {
-            stash_tile = a.stash + tile_idx * (long long)(64 * (KS0 + L * 16 * MT));
-            {
-                float* px = stash_tile + lane;
-                asm volatile("" : "+v"(px));
-#pragma unroll
-                for (int s = 0; s < KS0; ++s) px[s * 64] = X[s];
-            }
-            stash_tile += 64 * KS0;
-        }
+        LfgcSampler<CH, NF> sampler;
+        sampler.issue(a, nc, N, s_coord, hh);           // 8 corner rows requested; used after the layer-0 barrier
 
         auto acquire = [&](int l) -> const float* {
             if (!STREAM) return s_w + (l == 0 ? 0 : BLK0 + (l - 1) * BLK1);
+            LFGC_STAMP(2 + 2 * (l < 6 ? l : 6));           // the layer before this acquire (or the input phase for l = 0 -> slot 1 below)
+#if LFGC_ABLATE & 8                                        // diagnostics: no weight streaming, no barriers (wrong results)
+            return s_w + (l & 1) * BLKMAX;
+#endif
+            // my pieces of this layer's block have landed (they are older than the sampler's loads, which stay in
+            // flight across the layer-0 barrier: vmcnt counts in issue order)
+#ifndef LFGC_LATE_BARRIER0
+            if (l == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (CH / 8)) : "memory");
+            else
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            LFGC_STAMP(1);                                  // wait for my DMA pieces
             __syncthreads();
+            LFGC_STAMP(3 + 2 * (l < 5 ? l : 5));            // barrier before layer l
             const float* blk = s_w + (step & 1) * BLKMAX;
             const int ln = (l + 1 == L) ? 0 : l + 1;
             if (ln != 0 || batch + gridDim.x < a.nbatches) {
@@ -381,12 +388,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             ++step;
             return blk;
         };
+        float* stash_tile = STASH ? a.stash + tile_idx * (long long)(64 * (KS0 + L * 16 * MT)) + 64 * KS0 : nullptr;
         auto stash_of = [&](int l) -> float* { return STASH ? stash_tile + (long long)l * (64 * 16 * MT) : nullptr; };
 
         float ydot = 0.0f, tmax = 0.0f;
         u32x4 Ahi[2 * MT], Alo[2 * MT], Bhi[2 * MT], Blo[2 * MT];
         LfgcCarry ca, cb;
         {   // layer 0
+#ifndef LFGC_LATE_BARRIER0
+            const float* blk = acquire(0);
+#endif
+            float X[8 * KS16_0];
+            {
+                float B0[KS0];
+                sampler.finish(hh, B0);
+#pragma unroll
+                for (int s = 0; s < KS0; ++s) X[s] = B0[s];
+#pragma unroll
+                for (int s = KS0; s < 8 * KS16_0; ++s) X[s] = 0.0f;
+            }
+            if (STASH) {
+                float* px = a.stash + tile_idx * (long long)(64 * (KS0 + L * 16 * MT)) + lane;
+                asm volatile("" : "+v"(px));
+#pragma unroll
+                for (int s = 0; s < KS0; ++s) px[s * 64] = X[s];
+            }
             u32x4 X0hi[KS16_0], X0lo[KS16_0];
 #pragma unroll
             for (int s = 0; s < KS16_0; ++s) {
@@ -395,7 +421,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
                 else { lfgc_cvt8(X + 8 * s, fh); fl = fh; }
                 X0hi[s] = __builtin_bit_cast(u32x4, fh); X0lo[s] = __builtin_bit_cast(u32x4, fl);
             }
+#ifdef LFGC_LATE_BARRIER0
             const float* blk = acquire(0);
+#endif
             if (L == 1)
                 lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT, false>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
                                                                             s_final, ydot, tmax, stash_of(0), j, hh, lane);
@@ -429,6 +457,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             }
         }
 
+        LFGC_STAMP(14);               // last layer
         float y = ydot + __shfl_xor(ydot, 32);
         y += s_final[HP];
         // range screen (header comment): an f16 overflow anywhere upstream has made y NaN; the last layer's
@@ -440,6 +469,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
         if (a.clamp) y = fminf(fmaxf(y, -1.0f), 1.0f);
         if (valid && hh == 0) a.out[n] = y;
     }
+#ifdef LFGC_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* dst = a.stamps + ((long long)blockIdx.x * WAVES + wave) * 20;
+        for (int k = 0; k < 16; ++k) dst[k] = st_acc[k];
+        dst[16] = __builtin_amdgcn_s_memtime() - st_t0;
+        dst[17] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    }
+#endif
 }
 
 template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT>

@@ -13,8 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, 'tools', 'microbench', 'ablate')
-MASKS = {'full': 0}
-FLAG_VARIANTS = {'full_slp': ['-fslp-vectorize']}
+MASKS = {'full': 0, 'no_gather_loads': 1, 'no_stream_no_barrier': 8, 'neither': 9}
+FLAG_VARIANTS = {}
 
 if sys.argv[1] == 'build':
     from latent_feature_grid_compression_amd.build import build_variant
