@@ -62,7 +62,10 @@ class Feature_Grid_Model(nn.Module):
         self.final_layer = nn.Linear(self.hidden_width, self.output_channel)
 
         # arithmetic of the layer GEMMs: 'f16x2' (f16 hi+lo split, 3 MFMAs per product, fp32 accumulate: same error
-        # level as fp32 against the reference, ~3x faster) or 'fp32' (exact f32 MFMA, no activation range limit)
+        # level as fp32 against the reference, ~3x faster; a pass in which any sample leaves the f16 range -- |pre-
+        # activation| >~ 800 or |grid feature| >= 65504, a diverged model -- is redone by the library on the exact build,
+        # so the result is reference-equivalent for any finite parameters: include/lfgc.h, lfgc_forward_f32 `status`)
+        # or 'fp32' (exact f32 MFMA throughout)
         self.precision = 'f16x2'
         self._grid_cache = None      # (key, channel-last dense grid) while parameters are unchanged (eval)
         self._pack_cache = None      # (key, packed MLP blob)
@@ -202,6 +205,14 @@ class Feature_Grid_Model(nn.Module):
             raise ValueError('expected positions of shape (N, %d), got %s' % (self.d_in, tuple(orig_shape)))
 
         weights, biases = self._mlp_params()
+        if not torch.is_grad_enabled():
+            # grad mode is decided HERE: inside an autograd Function's forward it always reads "off", and the parameters'
+            # requires_grad flags say nothing about it -- under no_grad (field_from_net, validation) no stash is written
+            # (it is ~2.2 KB per sample) and the eval clamp runs inside the kernel
+            y, _ = ops.forward_raw(self._descriptor(), grid_cl.detach(), self._packed(), pos=input.detach(),
+                                   clamp=not self.training, want_stash=False, precision=self.precision)
+            x = y.view(-1, 1)
+            return x if self.training else x.view(*orig_shape[:-1], 1)
         x = ops.SampleDecodeFn.apply(self._descriptor(), input, grid_cl, self._packed(), self.num_layer,
                                      self.precision, *weights, *biases)
 

@@ -3,11 +3,13 @@ arithmetic happens in liblfgc.so) and the two autograd Functions of the hot path
 from __future__ import annotations
 
 import ctypes
+import functools
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import MlpDesc, Positions, check
@@ -23,6 +25,35 @@ def _require_hip(*tensors: torch.Tensor) -> None:
 
 def _stream(t: torch.Tensor) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _cuda_tensors(objs):
+    for o in objs:
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                yield o
+        elif isinstance(o, (list, tuple)):
+            yield from _cuda_tensors(o)
+
+
+def _on_device(fn):
+    """Run a wrapper with the device of its tensor arguments current.  The library launches on the calling thread's
+    CURRENT device (and keeps its per-device caches by it), while the stream handle passed down belongs to the tensors'
+    device: a model on cuda:1 called while cuda:0 is current would otherwise launch on the wrong device.  Tensors living
+    on different devices are refused."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        dev = None
+        for t in _cuda_tensors(list(args) + list(kwargs.values())):
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise _lib.LfgcError('tensors on different devices (%s and %s) in one call of %s' % (dev, t.device, fn.__name__))
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapped
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -98,6 +129,7 @@ def filter_taps(filt: torch.Tensor):
     return taps
 
 
+@_on_device
 def idwt_level(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, target: Sequence[int]) -> torch.Tensor:
     """lll (C,d0,d1,d2), hf (C,7,d0,d1,d2) -> (C,t0,t1,t2)."""
     _require_hip(lll, hf, filter_rev)
@@ -113,6 +145,7 @@ def idwt_level(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, ta
     return out
 
 
+@_on_device
 def idwt_level_bwd(d_out: torch.Tensor, filter_rev: torch.Tensor, d: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
     """d_out (C,t0,t1,t2) -> (d_lll (C,d0,d1,d2), d_hf (C,7,d0,d1,d2))."""
     _require_hip(d_out, filter_rev)
@@ -127,6 +160,7 @@ def idwt_level_bwd(d_out: torch.Tensor, filter_rev: torch.Tensor, d: Sequence[in
     return d_lll, d_hf
 
 
+@_on_device
 def to_channel_last(grid_cf: torch.Tensor) -> torch.Tensor:
     """(C,D,H,W) -> (D,H,W,Cs), Cs = C rounded up to 8, pad channels zero."""
     _require_hip(grid_cf)
@@ -139,6 +173,7 @@ def to_channel_last(grid_cf: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_device
 def to_channel_first(grid_cl: torch.Tensor, C: int) -> torch.Tensor:
     """(D,H,W,Cs) -> (C,D,H,W)."""
     _require_hip(grid_cl)
@@ -156,6 +191,7 @@ def dwt_out_shape(n: Sequence[int]) -> List[int]:
     return [(n[a] + 2 + hi[a] - 4) // 2 + 1 for a in range(3)]
 
 
+@_on_device
 def dwt_level(data: torch.Tensor, filter_fwd: torch.Tensor) -> torch.Tensor:
     """data (C,n0,n1,n2) -> (C,8,d0,d1,d2)."""
     _require_hip(data, filter_fwd)
@@ -194,6 +230,7 @@ class DecodeVolumeFn(torch.autograd.Function):
             return out.clone() if out.data_ptr() == coeffs[0].data_ptr() else out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_out):
         C = ctx.dims[0][0]
         n_levels = len(ctx.dims) - 1
@@ -215,6 +252,7 @@ def _thr(v) -> float:
     return _NAN if v is None else float(v)
 
 
+@_on_device
 def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> torch.Tensor:
     """One IDWT level with the drop factors of its inputs folded in: mul_l (d0,d1,d2) / mul_h (7,d0,d1,d2) or None;
     thr None = plain product, a float = masked straight-through rule (see include/lfgc.h)."""
@@ -241,6 +279,7 @@ def idwt_level_drop(lll, hf, mul_l, thr_l, mul_h, thr_h, filter_rev, target) -> 
     return out
 
 
+@_on_device
 def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml, want_dmh, d, penalty_ptrs=None):
     """Adjoint of idwt_level_drop -> (d_lll, d_hf, d_mul_l or None, d_mul_h or None).  want_dml / want_dmh: False, True
     (a zero tensor is allocated) or a ZERO-FILLED tensor of the factor's shape to accumulate into.  penalty_ptrs: None or
@@ -267,6 +306,7 @@ def idwt_level_drop_bwd(d_out, filter_rev, lll, hf, mul_l, mul_h, want_dml, want
     return d_lll, d_hf, d_ml, d_mh
 
 
+@_on_device
 def drop_apply(x: torch.Tensor, mul: torch.Tensor, thr=None) -> torch.Tensor:
     """x (C, ...) * mul (...) with the value rule of include/lfgc.h (one drop layer outside the decode)."""
     _require_hip(x, mul)
@@ -283,12 +323,15 @@ class DropApplyFn(torch.autograd.Function):
     """A drop layer's own forward(x): value by the layer's rule, gradients d_x = g*m, d_m = sum_c g*x."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, x, mul, thr):
         ctx.save_for_backward(x.detach(), mul.detach())
         ctx.need_dm = mul.requires_grad
         return drop_apply(x.detach(), mul.detach(), thr)
 
     @staticmethod
+    @once_differentiable
+    @_on_device
     def backward(ctx, g):
         x, mul = ctx.saved_tensors
         g, x, mul = _f32c(g), _f32c(x), _f32c(mul)
@@ -337,6 +380,7 @@ class DecodeVolumeDropFn(torch.autograd.Function):
             return decode_levels_drop(det, fdet, list(thresholds), ctx.shape_array, filter_rev, ctx.channel_last)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_out):
         d_coef, d_fac = _decode_drop_backward(ctx, d_out, None)
         return (None, None, None, None, None) + tuple(d_coef) + tuple(d_fac)
@@ -390,6 +434,7 @@ class DecodeVolumePenaltyFn(torch.autograd.Function):
     factors that ARE the penalised parameter, e.g. Smallify betas."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, filter_rev, shape_array, channel_last, thresholds, n, l1_flags, *tensors):
         coeffs, factors = tensors[:n], tensors[n:]
         ctx.set_materialize_grads(False)
@@ -416,6 +461,7 @@ class DecodeVolumePenaltyFn(torch.autograd.Function):
         return grid, pen
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_out, d_pen):
         if d_out is None:
             raise RuntimeError('the decoded grid took no part in the loss (only its penalties did): unsupported')
@@ -423,6 +469,7 @@ class DecodeVolumePenaltyFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(d_coef) + tuple(d_fac)
 
 
+@_on_device
 def sign_variance_update(betas: torch.Tensor, ema: torch.Tensor, emavar: torch.Tensor, momentum: float) -> None:
     """In-place EMA / EMA-variance step of the Smallify sign tracker (model/Smallify_Dropout.py:106-112)."""
     _require_hip(betas, ema, emavar)
@@ -433,6 +480,7 @@ def sign_variance_update(betas: torch.Tensor, ema: torch.Tensor, emavar: torch.T
                                                     b.numel(), _stream(b)), 'lfgc_sign_variance_update_f32')
 
 
+@_on_device
 def sign_variance_update_multi(betas, emas, emavars, momentum: float) -> None:
     """sign_variance_update for all drop layers of a model in one launch."""
     bs = [_f32c(b.detach()) for b in betas]
@@ -469,6 +517,7 @@ class PenaltyFn(torch.autograd.Function):
     apply(kinds, *tensors) -> fp32 (len(kinds),); a DKL term consumes two tensors (log_thetas, log_var)."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, kinds, *tensors):
         kinds = [int(k) for k in kinds]
         terms, keep = _penalty_terms(kinds, tensors)
@@ -480,6 +529,8 @@ class PenaltyFn(torch.autograd.Function):
         return sums[:len(kinds)].float()
 
     @staticmethod
+    @once_differentiable
+    @_on_device
     def backward(ctx, d_sums):
         tensors = ctx.saved_tensors
         terms, keep = _penalty_terms(ctx.kinds, tensors)
@@ -504,6 +555,7 @@ def penalty_sums(kinds, tensors) -> torch.Tensor:
 
 # ---- fused sample + embed + MLP ------------------------------------------------------------------------
 
+@_on_device
 def pack_mlp(desc: MlpDesc, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
     lib = _lib.load()
     ws = [_f32c(w.detach()) for w in weights]
@@ -534,6 +586,7 @@ def _positions_struct(pos: Optional[torch.Tensor], lattice=None) -> Tuple[Positi
     return ps, (int(x_end) - int(x_begin)) * int(res[1]) * int(res[2])
 
 
+@_on_device
 def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos: Optional[torch.Tensor] = None,
                 lattice=None, clamp: bool = False, want_stash: bool = False, out: Optional[torch.Tensor] = None,
                 precision: str = 'f16x2', range_fallback: bool = True, return_status: bool = False):
@@ -567,6 +620,7 @@ def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos:
     return out, stash
 
 
+@_on_device
 def backward_raw(desc: MlpDesc, grid_cl, packed, pos, stash, d_out, weights, biases, need_d_pos: bool,
                  precision: str = 'f16x2'):
     lib = _lib.load()
@@ -608,6 +662,7 @@ class SampleDecodeFn(torch.autograd.Function):
         return y.view(-1, 1)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_y):
         pos, grid_cl, packed, stash = ctx.saved_tensors[:4]
         params = ctx.saved_tensors[4:]
@@ -630,6 +685,7 @@ def _select_workspace(n: int, device) -> torch.Tensor:
     return torch.empty((nbytes + 7) // 8, dtype=torch.int64, device=device)
 
 
+@_on_device
 def codec_mask(x: torch.Tensor) -> torch.Tensor:
     """uint8 (ceil(n/8),): bit i (MSB first) = x.flat[i] != 0."""
     x = _flat_f32(x)
@@ -638,6 +694,7 @@ def codec_mask(x: torch.Tensor) -> torch.Tensor:
     return mask
 
 
+@_on_device
 def codec_compact(x: torch.Tensor) -> torch.Tensor:
     """The non-zero values of x in order (1-D).  Synchronises once to learn their number."""
     x = _flat_f32(x)
@@ -649,6 +706,7 @@ def codec_compact(x: torch.Tensor) -> torch.Tensor:
     return out[:int(count.item())]
 
 
+@_on_device
 def codec_expand(mask: torch.Tensor, bit_offset: int, n: int, values: torch.Tensor) -> torch.Tensor:
     """(n,) fp32: values scattered to the set bits [bit_offset, bit_offset + n) of the MSB-first mask, zeros elsewhere."""
     _require_hip(mask, values)
@@ -664,6 +722,7 @@ def codec_expand(mask: torch.Tensor, bit_offset: int, n: int, values: torch.Tens
     return out
 
 
+@_on_device
 def codec_kmeans(x: torch.Tensor, k: int = 256, iterations: int = 40) -> Tuple[torch.Tensor, torch.Tensor]:
     """(centres (k,) fp32 sorted, labels (n,) uint8) of the 1-D value set x.  Initial centres: Ward merging (host C++,
     lfgc_codec_ward_init_host) of a sorted strided sample of at most 2^16 values; then Lloyd iterations over all values
@@ -688,6 +747,7 @@ def codec_kmeans(x: torch.Tensor, k: int = 256, iterations: int = 40) -> Tuple[t
     return centres, labels
 
 
+@_on_device
 def codec_dequant(packed: torch.Tensor, bits: int, n: int, centres: torch.Tensor) -> torch.Tensor:
     """(n,) fp32 = centres[label_i], labels `bits` wide, MSB first, in the uint8 stream `packed`."""
     _require_hip(packed, centres)
@@ -704,6 +764,7 @@ def codec_dequant(packed: torch.Tensor, bits: int, n: int, centres: torch.Tensor
 
 # ---- ground truth / statistics -------------------------------------------------------------------------
 
+@_on_device
 def gt_interp(p: torch.Tensor, f: torch.Tensor, min_bb, max_bb, res) -> torch.Tensor:
     lib = _lib.load()
     _require_hip(p, f)
@@ -722,6 +783,7 @@ class GtMseLossFn(torch.autograd.Function):
     with the three bounds as host sequences of 3 floats."""
 
     @staticmethod
+    @_on_device
     def forward(ctx, pred, p, f, min_bb, max_bb, res):
         lib = _lib.load()
         _require_hip(pred, p, f)
@@ -742,6 +804,7 @@ class GtMseLossFn(torch.autograd.Function):
         return loss
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         (d_pred,) = ctx.saved_tensors
         return (d_pred * g).view(ctx.shape), None, None, None, None, None
@@ -751,6 +814,7 @@ def gt_mse_loss(pred, p, f, min_bb, max_bb, res) -> torch.Tensor:
     return GtMseLossFn.apply(pred, p, f, min_bb, max_bb, res)
 
 
+@_on_device
 def lattice_positions(flat: torch.Tensor, res, min_idx, max_idx, scales) -> Tuple[torch.Tensor, torch.Tensor]:
     """(raw (N,3), norm (N,3)) for flat voxel indices on the device: lfgc_lattice_positions_f32."""
     _require_hip(flat)
@@ -765,6 +829,7 @@ def lattice_positions(flat: torch.Tensor, res, min_idx, max_idx, scales) -> Tupl
     return raw, norm
 
 
+@_on_device
 def deviation_partial(pred: torch.Tensor, gt: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
     """acc = [sum sq, sum abs, min gt, max gt] (fp64, device)."""
     lib = _lib.load()

@@ -494,3 +494,109 @@ def test_reduced_precision_f16_mode(dev, name):
         y = m(torch.from_numpy(g['pos']).to(dev))
     err = rel_err(y.cpu().numpy(), g['y'])
     assert 1e-6 < err <= 3e-3, err          # really the reduced arithmetic, and within its bound
+
+
+def _oracle_forward(sm, pos):
+    dense = R.decode_volume(sm['coeffs'], sm['shape_array'], sm['filter_rev'])
+    return R.forward_from_grid(dense, sm['weights'], sm['biases'], pos, 2).numpy()
+
+
+@pytest.mark.parametrize('where', ['layer1_weights', 'layer3_weights', 'grid_features'])
+def test_default_precision_is_range_safe(dev, where):
+    """The reference computes in fp32 and stays finite for any finite parameters (model/Feature_Grid_Model.py:12-13,
+    :72-78).  The default f16-split arithmetic has a range (|pre-activation| <~ 800, |feature| < 65504): a pass that
+    leaves it must come back reference-equivalent all the same (exact-fp32 redo predicated on the kernel's status word),
+    never as NaN or as a finite wrong number."""
+    from latent_feature_grid_compression_amd import ops
+    C, G, H, L = 16, 16, 64, 4
+    m, sm = build_synth(C, G, H, L, seed=77, dev=dev)
+    with torch.no_grad():
+        if where == 'layer1_weights':          # layer-2 pre-activations ~1e5 (>= 7e4: VERDICT r1 item 1)
+            m.net_layers[1].weight.mul_(3.0e4)
+            sm['weights'][1] = sm['weights'][1] * 3.0e4
+        elif where == 'layer3_weights':        # the LAST hidden layer: no f16 conversion downstream, explicit screen
+            m.net_layers[3].weight.mul_(2.0e4)
+            sm['weights'][3] = sm['weights'][3] * 2.0e4
+        else:                                  # grid features beyond the f16 range (U(0,1) * 4e5), the network function
+            for p in m.feature_grid:             # itself kept well conditioned: layer 0 scales them back
+                p.mul_(4.0e5)
+            sm['coeffs'] = [c * 4.0e5 for c in sm['coeffs']]
+            m.net_layers[0].weight[:, 15:].mul_(2.5e-6)
+            sm['weights'][0] = sm['weights'][0].clone()
+            sm['weights'][0][:, 15:] *= 2.5e-6
+    rng = np.random.default_rng(5)
+    pos = torch.from_numpy(rng.uniform(-1, 1, (3000, 3)).astype(np.float32))
+    yref = _oracle_forward(sm, pos)
+    assert np.isfinite(yref).all()
+    m.train()
+    with torch.no_grad():
+        y = m(pos.to(dev)).cpu().numpy()                                   # default precision, default (safe) path
+        m.precision = 'fp32'
+        y32 = m(pos.to(dev)).cpu().numpy()
+    assert np.isfinite(y).all()
+    assert rel_err(y32, yref) <= 1e-5
+    assert rel_err(y, yref) <= 1e-5
+    # what the fast kernel alone does with such a pass: it flags it, and returns NaN -- not a finite wrong value --
+    # for the samples it could not do
+    m.precision = 'f16x2'
+    with torch.no_grad():
+        y_raw, _, status = ops.forward_raw(m._descriptor(), m._decoded_channel_last(), m._packed(), pos=pos.to(dev),
+                                           range_fallback=False, return_status=True)
+        y_ok, _, st_ok = ops.forward_raw(m._descriptor(), m._decoded_channel_last(), m._packed(), pos=pos.to(dev),
+                                         return_status=True)
+    assert status is None                                   # no status word asked for: nothing redone
+    y_raw = y_raw.cpu().numpy()
+    bad = ~np.isfinite(y_raw)
+    assert bad.any()
+    good = ~bad
+    if good.any():
+        assert np.abs(y_raw[good] - yref.reshape(-1)[good]).max() <= 1e-5 * np.abs(yref).max()
+    assert int(st_ok.item()) == 1 and rel_err(y_ok.cpu().numpy(), yref) <= 1e-5
+    # ... and a well-behaved model leaves the status word clear
+    m2, sm2 = build_synth(C, G, H, L, seed=78, dev=dev)
+    with torch.no_grad():
+        _, _, st2 = ops.forward_raw(m2._descriptor(), m2._decoded_channel_last(), m2._packed(), pos=pos.to(dev), return_status=True)
+    assert int(st2.item()) == 0
+
+
+def test_range_fallback_also_rewrites_the_training_stash(dev):
+    """A training forward whose fast pass overflowed must hand the backward kernels the exact build's stash: gradients of
+    a diverged model equal the oracle's."""
+    C, G, H, L = 8, 8, 32, 3
+    m, sm = build_synth(C, G, H, L, seed=91, dev=dev)
+    with torch.no_grad():
+        m.net_layers[1].weight.mul_(4.0e3)
+        sm['weights'][1] = sm['weights'][1] * 4.0e3
+    rng = np.random.default_rng(6)
+    pos = torch.from_numpy(rng.uniform(-1, 1, (512, 3)).astype(np.float32))
+    m.train()
+    y = m(pos.to(dev))
+    y.square().mean().backward()
+    leaves = [t.clone().requires_grad_(True) for t in sm['coeffs'] + sm['weights'] + sm['biases']]
+    nc = len(sm['coeffs'])
+    yr = R.forward(leaves[:nc], sm['shape_array'], sm['filter_rev'], leaves[nc:nc + L + 1], leaves[nc + L + 1:], pos, 2)
+    yr.square().mean().backward()
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().numpy()) <= 1e-5
+    ours = [p.grad for p in m.feature_grid] + [l.weight.grad for l in list(m.net_layers) + [m.final_layer]]
+    refs = [t.grad for t in leaves[:nc + L + 1]]
+    for g, r in zip(ours, refs):
+        assert torch.isfinite(g).all()
+        # |a| ~ 1e3 here: snake'(a) = 0.5 + sin 2a amplifies the fp32 rounding of a (1e-4 absolute) -- two fp32 evaluation
+        # orders of such a model agree to ~1e-4 of the gradient's scale at best; a wrong (overflowed) stash would be off by O(1)
+        assert (g.cpu() - r).abs().max() <= 1e-3 * r.abs().max()
+
+
+def test_non_current_device_is_respected(dev):
+    """A model on cuda:1 called while cuda:0 is the current device must launch on cuda:1 (ops._on_device)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one visible device')
+    d1 = torch.device('cuda:1')
+    m, sm = build_synth(16, 16, 32, 2, seed=11, dev=d1)
+    pos = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (1000, 3)).astype(np.float32))
+    assert torch.cuda.current_device() == 0
+    with torch.no_grad():
+        y = m.train()(pos.to(d1)).cpu().numpy()
+    assert rel_err(y, _oracle_forward(sm, pos)) <= 1e-5
+    from latent_feature_grid_compression_amd import _lib
+    with pytest.raises(_lib.LfgcError, match='different devices'):
+        m(pos.to(dev))
