@@ -11,13 +11,18 @@ Fourier-embed + 4-layer SnakeAlt MLP forward over every voxel of a 256^3 lattice
 positions generated per tile on device), fp32.  Model = BASELINE configs[2]/[3] shape (64^3 x 32-channel
 grid, 4-level db2 wavelet code, MLP 4 x 128), synthetic random-init parameters (no datasets offline).
 With N > 1 ranks the tile lattice is cut into contiguous x-slabs (strong scaling: the volume is fixed)
-and the output volume is assembled with ONE RCCL all-gather over xGMI.
+and the output volume is assembled on rank 0 with an RCCL gather over xGMI (`--gather all`: on every rank);
+the other assembly mode, per-rank kernel / decode+pack / gather-wait times and the world size RCCL saw are
+reported in `multi_gpu`.
 
-Rank 0 prints one JSON line.  `roofline` is for the dominant kernel (lfgc_fwd_kernel): algorithmic fp32
+Rank 0 prints one JSON line.  `roofline` is for the dominant kernel (lfgc_fwd16_kernel): algorithmic fp32
 MLP FLOPs per launch / its average launch duration (HIP events on the launch stream) against the dense
-fp32 MFMA peak; the HBM-side figure on the algorithmic gather bytes is reported next to it.
+peak of the matrix pipe the build runs on (2.5 PFLOP/s f16 for the default build; the MFMA work actually
+executed -- three f16 products per fp32 product -- is `executed_mfma`); the HBM-side figure on the
+algorithmic gather bytes is `hbm_algorithmic`, the measured HBM traffic per launch `traffic`.
 `cpu_baseline` times the oracle's op-for-op PyTorch restatement of the reference on the host cores for a
-bounded sample of the same workload (rank 0, N = 1 only).
+bounded sample of the same workload (rank 0, N = 1 only).  `extra` (N = 1) puts the other BASELINE
+configs under the same clock: cfg 2 and cfg 5 forward + decode, the cfg-3 train step (default and reduced).
 """
 import argparse
 import json
@@ -36,10 +41,23 @@ if ROOT not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32-input MFMA
 F16_MFMA_PEAK_TFLOPS = 2500.0      # same guide, dense BF16/F16 MFMA
-# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r1/*pmc_hbm*.json):
-# 2 x FETCH_SIZE (gfx950 correction for 16-B/lane reads) + WRITE_SIZE, per (workload, precision); None = not collected
-TRAFFIC_BYTES = {('headline', 'f16x2'): 375089621, ('headline', 'fp32'): 371095253}
 HBM_PEAK_GBS = 8000.0              # same guide, HBM3E spec
+
+
+def traffic_bytes(workload, precision):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs for
+    FETCH_SIZE and WRITE_SIZE; bytes = 2 x FETCH_SIZE KB (gfx950 correction for 16-B/lane reads) + WRITE_SIZE KB), or
+    None when no profile of this (workload, build) is committed.  Newest round first."""
+    for rnd in ('r2', 'r1'):
+        path = os.path.join(ROOT, 'profiles', rnd, 'bench_headline_pmc.json')
+        try:
+            with open(path) as fh:
+                hbm = json.load(fh).get('hbm', {})
+        except (OSError, ValueError):
+            continue
+        if workload == 'headline' and precision in hbm:
+            return hbm[precision].get('hbm_bytes_per_launch')
+    return None
 
 WORKLOADS = {
     # name: (volume edge, grid channels C, grid edge G, hidden H, layers L)
@@ -127,10 +145,107 @@ def cpu_baseline(model, w, budget_s=20.0, hip_volume=None):
     return {
         'parity': parity, 'cpu_model': cpu_model, 'host_threads_visible': os.cpu_count(),
         'value': n_samples / t_fwd / 1e6, 'unit': 'Msamples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-        'sample': '%d tiles of 32^3 (%d samples) of the same lattice, grid decoded once (%.3f s, not included); '
-                  'with the reference\'s per-tile decode: %.4f Msamples/s'
-                  % (n_tiles, n_samples, t_decode, n_samples / (t_fwd + n_tiles * t_decode) / 1e6),
+        # the reference decodes the whole grid again for every 32^3 tile (model/Feature_Grid_Model.py:54): its actual rate
+        'value_with_per_tile_decode': n_samples / (t_fwd + n_tiles * t_decode) / 1e6,
+        'decode_s': t_decode,
+        'sample': '%d tiles of 32^3 (%d samples) of the same lattice; value = grid decoded once (%.3f s, not included), '
+                  'value_with_per_tile_decode = the reference\'s behaviour (decode per tile)' % (n_tiles, n_samples, t_decode),
     }
+
+
+def _event_ms(fn, reps):
+    """Average device time of fn() over reps calls, HIP events on the current stream."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def forward_extra(name, device, precision='f16x2', reps=3):
+    """One more BASELINE shape under the same clock: full-volume fused forward of workload `name` (+ its decode)."""
+    from latent_feature_grid_compression_amd import ops
+    w = WORKLOADS[name]
+    model = build_model(w, seed=2003, device=device)
+    model.precision = precision
+    res = (w['vol'],) * 3
+    n = w['vol'] ** 3
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    with torch.no_grad():
+        def decode():
+            model._grid_cache = None
+            return model._decoded_channel_last()
+        grid = decode()
+        packed = model._packed()
+        fwd = lambda: ops.forward_raw(model._descriptor(), grid, packed, lattice=(res, 0, w['vol'], 32), clamp=True, out=out,
+                                      precision=precision)
+        fwd()
+        torch.cuda.synchronize()
+        k_ms = _event_ms(fwd, reps)
+        d_ms = _event_ms(decode, reps)
+    assert bool(torch.isfinite(out[::4097]).all())
+    bps = 12 + 4 + 8 * w['C'] * 4
+    K0 = 3 + 12 + w['C']
+    fl = 2 * (K0 * w['H'] + (w['L'] - 1) * w['H'] ** 2 + w['H'])
+    del out, grid, model
+    torch.cuda.empty_cache()
+    return {'workload': w['desc'], 'precision': precision, 'samples': n, 'kernel_ms': k_ms, 'decode_ms': d_ms,
+            'value': n / (k_ms * 1e-3) / 1e6, 'unit': 'Msamples/s (forward launch only; decode_ms beside it)',
+            'algorithmic_TFLOPs': fl * n / (k_ms * 1e-3) / 1e12,
+            'hbm_algorithmic': {'bytes_per_sample': bps, 'achieved_GBs': bps * n / (k_ms * 1e-3) / 1e9,
+                                'frac': bps * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+
+def train_step_extra(device, precision='f16x2', steps=100, warmup=10):
+    """BASELINE config 3 train step (training/training.py:95-138): 32 768 lattice samples of a 255^3 volume -> forward ->
+    ground truth + MSE -> backward -> Adam(lr 0.008, torch fused), the whole step captured in one HIP graph and replayed."""
+    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_mse_loss
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    w = WORKLOADS['headline']
+    model = build_model(w, seed=2003, device=device).train()
+    model.precision = precision
+    rng = np.random.Generator(np.random.PCG64(1003))
+    vol = torch.from_numpy(rng.uniform(-1, 1, (255, 255, 255)).astype(np.float32)).to(device)
+    ds = IndexDataset((255, 255, 255), 16, build_index_table=False)
+    opt = torch.optim.Adam(model.parameters(), lr=0.008, capturable=True, fused=True)
+    n = 2048 * 16
+    mn_h, mx_h, rs_h = ds.min_idx.tolist(), ds.max_idx.tolist(), ds.vol_res.tolist()
+    ds.min_idx, ds.max_idx, ds.scales = ds.min_idx.to(device), ds.max_idx.to(device), ds.scales.to(device)
+
+    def step():
+        flat = torch.randint(0, ds.n_voxels, (n,), device=device)
+        raw, norm = ds.positions_from_flat(flat)
+        norm.requires_grad = True                      # the reference sets requires_grad on positions (training.py:99)
+        opt.zero_grad()
+        loss = trilinear_mse_loss(model(norm).squeeze(-1), raw, vol, mn_h, mx_h, rs_h)
+        loss.backward()
+        opt.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        loss = step()
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    ms = _event_ms(graph.replay, steps)
+    final = float(loss.detach())
+    del graph, opt, model, vol
+    torch.cuda.empty_cache()
+    return {'workload': 'cfg3 train step: 64^3x32ch grid (4-level db2), MLP 4x128, 32768 lattice samples of 255^3, '
+                        'fwd + GT + MSE + bwd + fused Adam, one HIP graph', 'precision': precision, 'samples': n,
+            'ms_per_step': ms, 'value': n / (ms * 1e-3) / 1e6, 'unit': 'Msamples/s', 'steps': steps, 'final_loss': final}
+
+
 
 
 def main():
@@ -141,7 +256,10 @@ def main():
     ap.add_argument('--workload', default='headline', choices=sorted(WORKLOADS))
     ap.add_argument('--precision', default='f16x2', choices=['f16x2', 'fp32', 'f16'],
                     help="layer-GEMM arithmetic: 'f16x2' (default, f16 hi+lo split on the f16 matrix pipe) or 'fp32' (exact f32 MFMA)")
+    ap.add_argument('--gather', default='root', choices=['root', 'all'],
+                    help="N > 1: how the volume is assembled for `value` (the other mode is timed beside it)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the other BASELINE configs (cfg 2, cfg 5, cfg-3 train step)')
     ap.add_argument('--no-check', action='store_true', help='skip the finite-output check (ablation builds)')
     args = ap.parse_args()
 
@@ -168,20 +286,24 @@ def main():
     model.precision = args.precision
     ds = IndexDataset((w['vol'],) * 3, 16, build_index_table=False)
     res = ds.vol_res_touple
-    parts = V.slab_partition(res[0], world, 32)
-    my_b, my_e = parts[rank]
-    my_samples = (my_e - my_b) * res[1] * res[2]
 
     ev = []                                   # (start, end, samples) per timed launch of the dominant kernel
-    step_state = {'i': -1}
+    ev_prep = []                              # (start, end) per timed decode + pack
+    state = {'timed': False}
 
     def slab_fn(b, e, out_view):
-        # the fused forward of this rank's slab; events bracket exactly the dominant kernel's launch
+        # the fused forward of this rank's slab; events bracket exactly the dominant kernel's launch (and, apart from
+        # it, the wavelet decode + parameter pack that every pass repeats)
         with torch.no_grad():
+            timed = state['timed']
+            if timed:
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
             grid_cl = model._decoded_channel_last()
             packed = model._packed()
-            timed = step_state['i'] >= 0
             if timed:
+                p1.record()
+                ev_prep.append((p0, p1))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             ops.forward_raw(model._descriptor(), grid_cl, packed, pos=None, lattice=(res, b, e, 32), clamp=True,
@@ -190,37 +312,63 @@ def main():
                 e1.record()
                 ev.append((e0, e1, (e - b) * res[1] * res[2]))
 
-    def one_step():
+    def one_step(gather, tm=None):
         model._grid_cache = None          # every pass decodes the wavelet-coded grid and re-packs: no cached outputs
         model._pack_cache = None
-        return V.reconstruct_volume_sharded(ds, model, 32, slab_fn=slab_fn, device=device)
+        return V.reconstruct_volume_sharded(ds, model, 32, slab_fn=slab_fn, device=device, gather=gather, timings=tm)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        vol = one_step()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step_state['i'] = i
-        vol = one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    step_state['i'] = -1
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
-    assert tuple(vol.shape) == tuple(res) and (args.no_check or bool(torch.isfinite(vol).all()))
+    def timed_loop(gather, steps, collect):
+        for _ in range(args.warmup):
+            vol = one_step(gather)
+        sync()
+        state['timed'] = collect
+        waits = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tm = {} if (collect and world > 1) else None
+            vol = one_step(gather, tm)
+            if tm:
+                waits.append(tm['gather_wait_ms'])
+        sync()
+        elapsed = time.perf_counter() - t0
+        state['timed'] = False
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item(), vol, waits
+
+    elapsed, vol, waits = timed_loop(args.gather, args.steps, True)
+    total_samples = res[0] * res[1] * res[2]
+    value = total_samples * args.steps / elapsed / 1e6
+    if vol is not None:
+        assert tuple(vol.shape) == tuple(res) and (args.no_check or bool(torch.isfinite(vol).all()))
 
     kern_total_ms = float(sum(a.elapsed_time(b) for a, b, _ in ev))
     kern_samples = int(sum(n for _, _, n in ev))
     kern_ms = kern_total_ms / max(len(ev), 1)
-    total_samples = res[0] * res[1] * res[2]
-    value = total_samples * args.steps / elapsed / 1e6
+    prep_ms = float(sum(a.elapsed_time(b) for a, b in ev_prep)) / max(len(ev_prep), 1)
+
+    multi = None
+    if world > 1:
+        # per-rank attribution (events on each rank's own stream) + the other assembly mode under the same clock
+        mine = torch.tensor([kern_ms * len(ev) / max(args.steps, 1), prep_ms, float(np.mean(waits)) if waits else 0.0],
+                            dtype=torch.float64, device=device)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        other = 'all' if args.gather == 'root' else 'root'
+        o_steps = max(3, args.steps // 2)
+        o_elapsed, _, _ = timed_loop(other, o_steps, False)
+        multi = {'world_size': dist.get_world_size(), 'backend': dist.get_backend(), 'gather': args.gather,
+                 'per_rank': {'kernel_ms_per_step': [float(t[0]) for t in allr], 'decode_pack_ms': [float(t[1]) for t in allr],
+                              'gather_wait_ms': [float(t[2]) for t in allr]},
+                 'bytes_received_by_root_per_step': 4 * total_samples * (world - 1) // world,
+                 'other_mode': {'gather': other, 'value': total_samples * o_steps / o_elapsed / 1e6,
+                                'ms_per_step': o_elapsed / o_steps * 1e3, 'steps': o_steps}}
 
     if rank == 0:
         K0 = 3 + 12 + w['C']
@@ -230,8 +378,9 @@ def main():
         hbm_alg_gbs = bytes_per_sample * kern_samples / (kern_total_ms * 1e-3) / 1e9
         split = model.precision == 'f16x2'
         half = model.precision == 'f16'          # reduced-precision opt-in: NOT the headline configuration
-        # f16x2: every fp32 product block is three f16 MFMAs -> fp32-equivalent ceiling = f16 dense peak / 3
-        peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else (F16_MFMA_PEAK_TFLOPS if half else FP32_MFMA_PEAK_TFLOPS)
+        # the matrix pipe the build runs on: dense f16 MFMA (2.5 PFLOP/s) for both f16 builds, f32-input MFMA for 'fp32'
+        peak = FP32_MFMA_PEAK_TFLOPS if model.precision == 'fp32' else F16_MFMA_PEAK_TFLOPS
+        executed = achieved_tflops * (3.0 if split else 1.0)
         out = {
             'metric': 'Msamples/s (grid-interp+embed+MLP fwd) on 256^3 volume' if args.workload == 'headline'
                       else 'Msamples/s (grid-interp+embed+MLP fwd)',
@@ -242,21 +391,26 @@ def main():
                       'f16 GEMM inputs, f32 accumulate (REDUCED precision, not the headline configuration)' if half else 'f32'),
             'data': 'synthetic',
             'config': {'workload': w['desc'], 'samples_per_step': total_samples, 'tiles': 'x-slabs of 32^3 tiles',
-                       'parallelism': 'tile-slab x%d, chunked all-gather overlapped with compute' % world if world > 1 else 'single GPU',
-                       'step_includes': 'wavelet decode + param pack + fused forward' + (' + RCCL all-gather' if world > 1 else '')},
+                       'parallelism': ('tile-slab x%d, pieces gathered to %s (RCCL) under the next piece\'s compute'
+                                       % (world, 'rank 0' if args.gather == 'root' else 'every rank')) if world > 1 else 'single GPU',
+                       'step_includes': 'wavelet decode + param pack + fused forward' + (' + RCCL gather' if world > 1 else '')},
+            # bound: the MLP contractions (110 592 algorithmic FLOP per sample) on the f16 matrix pipe; `achieved` counts
+            # ALGORITHMIC fp32 FLOPs, `peak` is the dense peak of the pipe the build executes on (no credit for the 3x
+            # emulation work: that is `executed_mfma`).  The HBM-side figure on algorithmic bytes is beside it.
             'roofline': {'bound': 'mfma', 'achieved': achieved_tflops, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved_tflops / peak, 'traffic': TRAFFIC_BYTES.get((args.workload, model.precision)),
+                         'frac': achieved_tflops / peak, 'traffic': traffic_bytes(args.workload, model.precision),
                          'kernel': 'lfgc_fwd16_kernel' if (split or half) else 'lfgc_fwd_kernel', 'kernel_ms': kern_ms,
                          'launches_per_step': len(ev) // max(args.steps, 1),
                          'samples_per_launch': kern_samples // max(len(ev), 1), 'flop_per_sample': flop_per_sample,
-                         'peak_note': ('fp32-equivalent ceiling of the f16-split GEMM: 2500 TFLOP/s dense f16 MFMA / 3 '
-                                       'MFMAs per fp32 product block; executed f16 MFMA rate = 3 x achieved'
-                                       if split else 'dense f16 MFMA, one product per block' if half
-                                       else 'dense f32-input MFMA (v_mfma_f32_32x32x2_f32)'),
-                         'vs_fp32_mfma_peak': achieved_tflops / FP32_MFMA_PEAK_TFLOPS,
+                         'executed_mfma': {'TFLOPs': executed, 'frac_of_peak': executed / peak,
+                                           'note': ('three f16 MFMAs per fp32 product block (hi/lo split)' if split else
+                                                    'one MFMA per product block')},
+                         'decode_pack_ms': prep_ms,
                          'hbm_algorithmic': {'bytes_per_sample': bytes_per_sample, 'achieved_GBs': hbm_alg_gbs,
                                              'peak_GBs': HBM_PEAK_GBS, 'frac': hbm_alg_gbs / HBM_PEAK_GBS}},
         }
+        if multi is not None:
+            out['multi_gpu'] = multi
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(model, w, hip_volume=vol)
             if split:
@@ -264,18 +418,34 @@ def main():
                 # how far the default build's volume is from it
                 model.precision = 'fp32'
                 for _ in range(2):
-                    v32 = one_step()
+                    v32 = one_step('all')
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(5):
-                    v32 = one_step()
+                    v32 = one_step('all')
                 torch.cuda.synchronize()
                 dt = (time.perf_counter() - t0) / 5
                 out['exact_fp32_build'] = {'value': total_samples / dt / 1e6, 'unit': 'Msamples/s', 'ms_per_step': dt * 1e3,
                                            'max_rel_diff_of_default_build': float((vol - v32).abs().max() / v32.abs().max())}
                 model.precision = 'f16x2'
+                del v32
         else:
             out['cpu_baseline'] = None
+        if world == 1 and not args.no_extra and args.workload == 'headline':
+            # every other BASELINE config under the same clock (HIP events; sample counts given so value x time can be
+            # cross-checked): cfg 2 and cfg 5 forward + decode, the cfg-3 train step in the default and the reduced build
+            del vol
+            torch.cuda.empty_cache()
+            extra = {}
+            for key, fn in (('cfg2_forward', lambda: forward_extra('cfg2', device, args.precision, reps=10)),
+                            ('cfg5_forward', lambda: forward_extra('cfg5', device, args.precision, reps=2)),
+                            ('cfg3_train_step', lambda: train_step_extra(device, args.precision)),
+                            ('cfg3_train_step_reduced_f16', lambda: train_step_extra(device, 'f16'))):
+                try:
+                    extra[key] = fn()
+                except Exception as exc:                      # noqa: BLE001 -- an extra must not take the headline down
+                    extra[key] = {'error': '%s: %s' % (type(exc).__name__, exc)}
+            out['extra'] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

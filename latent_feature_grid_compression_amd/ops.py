@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -13,6 +14,9 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib
 from ._lib import MlpDesc, Positions, check
+
+
+_DEBUG_STATUS = bool(os.environ.get('LFGC_DEBUG_STATUS'))
 
 
 def _require_hip(*tensors: torch.Tensor) -> None:
@@ -615,6 +619,8 @@ def forward_raw(desc: MlpDesc, grid_cl: torch.Tensor, packed: torch.Tensor, pos:
                                _lib.PRECISION[precision], int(clamp), out.data_ptr(),
                                stash.data_ptr() if stash is not None else None,
                                status.data_ptr() if status is not None else None, _stream(grid_cl)), 'lfgc_forward_f32')
+    if _DEBUG_STATUS and status is not None:        # diagnostics: LFGC_DEBUG_STATUS=1 (synchronises)
+        print('[lfgc] forward n=%d precision=%s status=%d' % (n, precision, int(status.item())), flush=True)
     if return_status:
         return out, stash, status
     return out, stash

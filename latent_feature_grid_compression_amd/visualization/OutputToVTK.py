@@ -7,9 +7,9 @@
   (same fp32 operation order as the reference's host code) is generated inside the HIP kernel, so no
   positions are uploaded and nothing is copied back per tile.
 * ``reconstruct_volume_sharded`` cuts the tile lattice into contiguous x-slabs, one per rank
-  (torch.distributed, one process per GPU), and assembles the volume with ONE all-gather (RCCL over xGMI
-  on MI355X; gloo in the CPU tests).  Tiles are independent, the decoded grid is replicated: there is no
-  other communication.
+  (torch.distributed, one process per GPU), and assembles the volume with a gather to the root rank or an
+  all-gather (RCCL over xGMI on MI355X; gloo in the CPU tests), received straight into views of the output.
+  Tiles are independent, the decoded grid is replicated: there is no other communication.
 VTK file output (pyevtk) is out of scope.
 """
 from __future__ import annotations
@@ -126,17 +126,28 @@ def slab_partition(res_x: int, world_size: int, tiled_res: int = 32) -> List[Tup
 def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=None,
                                slab_fn: Optional[Callable[[int, int, torch.Tensor], None]] = None,
                                device: Optional[torch.device] = None, chunks: Optional[int] = None,
-                               always_gather: bool = False) -> torch.Tensor:
-    """Every rank evaluates its x-slab of tiles and the slabs are assembled with all-gathers; returns the full
-    (X,Y,Z) volume on every rank.
+                               always_gather: bool = False, gather: str = 'all', root: int = 0,
+                               timings: Optional[dict] = None) -> Optional[torch.Tensor]:
+    """Every rank evaluates its x-slab of tiles; the slabs are assembled over the process group (RCCL over xGMI on
+    MI355X, gloo in the CPU tests).
+
+    ``gather='root'``: a gather to rank ``root`` -- the only rank that assembles (and returns) the (X,Y,Z) volume, the
+    others return None; each rank's slab crosses the fabric once (what a writer of the volume needs).
+    ``gather='all'``: an all-gather -- every rank returns the full volume (world-1 times the bytes of 'root').
 
     The slab is cut into ``chunks`` pieces (default 4) of x-rows -- whole tile planes while there are enough of them,
-    multiples of 8 rows otherwise (8 ranks on 256^3 own one tile plane each) --; each piece is gathered with its own
-    ``all_gather_into_tensor`` issued asynchronously right after the piece's kernel launch, so the collective of piece
-    c (RCCL's stream, xGMI) runs under the compute of piece c+1.  ``chunks=1`` = one gather.
+    multiples of 8 rows otherwise (8 ranks on 256^3 own one tile plane each) --; each piece's collective is issued
+    asynchronously right after the piece's kernel launch, so the transfer of piece c runs under the compute of piece
+    c+1.  Pieces are received straight into views of the output volume (x is the slowest axis, so a piece of a slab is a
+    contiguous range of it); only a piece that is shorter than the common piece length (ragged volumes, e.g. 255^3 =
+    7 x 32 + 31) goes through a scratch buffer for its padding rows.  ``chunks=1`` = one collective.
 
     ``slab_fn(x_begin, x_end, out_view)`` fills ``out_view`` ((x_end-x_begin, Y, Z)); default = the fused HIP
-    forward of ``net``.  (The CPU/gloo tests inject a stub here: the HIP path itself has no CPU form.)"""
+    forward of ``net``.  (The CPU/gloo tests inject a stub here: the HIP path itself has no CPU form.)
+    ``timings``: a dict that receives 'compute_ms' (slab_fn calls, device time) and 'gather_wait_ms' (time this rank
+    spent waiting for the collectives after its last launch), measured with events on the current stream."""
+    if gather not in ('all', 'root'):
+        raise ValueError("gather must be 'all' or 'root'")
     res = dataset.vol_res_touple
     if dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -149,11 +160,28 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
     if slab_fn is None:
         def slab_fn(b, e, out_view):
             field_from_net_fused(dataset, net, b, e, tiled_res, out=out_view)
+    on_gpu = torch.device(device).type == 'cuda'
+    ev = []
+
+    def timed_slab(xb, xe, view):
+        if timings is not None and on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            slab_fn(xb, xe, view)
+            e1.record()
+            ev.append((e0, e1))
+        else:
+            slab_fn(xb, xe, view)
+
     b, e = parts[rank]
     if world == 1 and not always_gather:     # always_gather: run the collective path even alone (RCCL smoke test)
         out = torch.empty(res, dtype=torch.float32, device=device)
         if e > b:
-            slab_fn(b, e, out[b:e])
+            timed_slab(b, e, out[b:e])
+        if timings is not None:
+            if on_gpu:
+                torch.cuda.synchronize(device)
+            timings.update(compute_ms=float(sum(a.elapsed_time(c) for a, c in ev)), gather_wait_ms=0.0, world_size=1)
         return out
     # piece boundaries relative to the slab start, on tile planes, identical on every rank (from max_x)
     want = 4 if chunks is None else max(1, int(chunks))
@@ -162,25 +190,51 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
     n_chunks = max(1, min(units, want))
     cuts = [min(((c * units) // n_chunks) * unit, max_x) for c in range(n_chunks + 1)]
     cuts[-1] = max_x
-    bufs, works = [], []
+    assembles = gather == 'all' or rank == root
+    out = torch.empty(res, dtype=torch.float32, device=device) if assembles else None
+    works, fixups = [], []
     for c in range(n_chunks):
         lo, hi = cuts[c], cuts[c + 1]
-        mine = torch.empty((hi - lo, res[1], res[2]), dtype=torch.float32, device=device)
+        span = hi - lo
         xb, xe = min(b + lo, e), min(b + hi, e)
-        if xe - xb < hi - lo:
-            mine[xe - xb:].zero_()               # rows past this rank's (shorter) slab: padding of the equal-size gather
+        full_mine = xe - xb == span
+        # my piece: computed in place in the output volume when I assemble and the piece is whole
+        if assembles and full_mine:
+            mine = out[xb:xe]
+        else:
+            mine = torch.empty((span, res[1], res[2]), dtype=torch.float32, device=device)
+            if not full_mine:
+                mine[xe - xb:].zero_()               # rows past this rank's (shorter) slab: padding of the equal-size collective
         if xe > xb:
-            slab_fn(xb, xe, mine[:xe - xb])
-        gathered = torch.empty((world * (hi - lo), res[1], res[2]), dtype=torch.float32, device=device)
-        works.append(dist.all_gather_into_tensor(gathered, mine, group=group, async_op=True))
-        bufs.append((gathered, hi - lo))
+            timed_slab(xb, xe, mine[:xe - xb])
+        if assembles:
+            dests = []
+            for r, (rb, re_) in enumerate(parts):
+                take = max(0, min(re_ - rb - lo, span))
+                if r == rank and full_mine:
+                    dests.append(mine)
+                elif take == span:
+                    dests.append(out[rb + lo:rb + lo + span])
+                else:                               # short (or empty) piece: its padding rows need somewhere to land
+                    scratch = torch.empty((span, res[1], res[2]), dtype=torch.float32, device=device)
+                    dests.append(scratch)
+                    if take > 0:
+                        fixups.append((out[rb + lo:rb + lo + take], scratch, take))
+        if gather == 'all':
+            works.append(dist.all_gather(dests, mine, group=group, async_op=True))
+        else:
+            works.append(dist.gather(mine, gather_list=dests if rank == root else None, dst=root, group=group, async_op=True))
+    if timings is not None and on_gpu:
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
     for w in works:
         w.wait()
-    pieces = []
-    for r, (rb, re_) in enumerate(parts):
-        for c in range(n_chunks):
-            gathered, span = bufs[c]
-            take = max(0, min(re_ - rb - cuts[c], span))
-            if take > 0:
-                pieces.append(gathered[r * span:r * span + take])
-    return torch.cat(pieces, 0)
+    for dst, scratch, take in fixups:
+        dst.copy_(scratch[:take])
+    if timings is not None:
+        if on_gpu:
+            g1.record()
+            torch.cuda.synchronize(device)
+            timings.update(compute_ms=float(sum(a.elapsed_time(c) for a, c in ev)), gather_wait_ms=float(g0.elapsed_time(g1)))
+        timings.update(world_size=world, chunks=n_chunks, gather=gather)
+    return out

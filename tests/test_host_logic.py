@@ -169,7 +169,7 @@ def _free_port():
     return p
 
 
-def _gloo_worker(rank, world, port, res, out_dir, chunks=None):
+def _gloo_worker(rank, world, port, res, out_dir, chunks=None, gather='all'):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -186,18 +186,25 @@ def _gloo_worker(rank, world, port, res, out_dir, chunks=None):
         z = torch.arange(res[2], dtype=torch.float32).view(1, 1, -1)
         out_view.copy_(x * 10000 + y * 100 + z)
 
-    vol = reconstruct_volume_sharded(ds, None, 32, slab_fn=slab_fn, device=torch.device('cpu'), chunks=chunks)
-    torch.save({'vol': vol.clone(), 'calls': calls}, os.path.join(out_dir, 'rank%d.pt' % rank))
+    tm = {}
+    vol = reconstruct_volume_sharded(ds, None, 32, slab_fn=slab_fn, device=torch.device('cpu'), chunks=chunks,
+                                     gather=gather, root=world - 1 if gather == 'root' else 0, timings=tm)
+    assert tm['world_size'] == world and tm['gather'] == gather
+    torch.save({'vol': None if vol is None else vol.clone(), 'calls': calls}, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('gather', ['all', 'root'])
 @pytest.mark.parametrize('res,world,chunks', [((70, 9, 11), 2, None), ((33, 5, 4), 2, None), ((64, 6, 6), 2, 1),
                                               ((200, 4, 5), 2, 3), ((255, 3, 3), 3, None),
                                               ((64, 6, 6), 2, None), ((128, 3, 3), 4, None)])   # pieces finer than a tile plane
-def test_sharded_reconstruction_gloo(tmp_path, res, world, chunks):
+def test_sharded_reconstruction_gloo(tmp_path, res, world, chunks, gather):
+    """world_size 2..4 over gloo: the slabs tile the volume exactly once; with gather='all' every rank holds the whole
+    volume, with gather='root' only the root (here the LAST rank) does -- received straight into views of it, ragged
+    slabs (70 = 2x32+6, 255 = 7x32+31) through the padding scratch."""
     port = _free_port()
-    mp.spawn(_gloo_worker, args=(world, port, res, str(tmp_path), chunks), nprocs=world, join=True)
+    mp.spawn(_gloo_worker, args=(world, port, res, str(tmp_path), chunks, gather), nprocs=world, join=True)
     x = torch.arange(res[0], dtype=torch.float32).view(-1, 1, 1)
     y = torch.arange(res[1], dtype=torch.float32).view(1, -1, 1)
     z = torch.arange(res[2], dtype=torch.float32).view(1, 1, -1)
@@ -205,7 +212,10 @@ def test_sharded_reconstruction_gloo(tmp_path, res, world, chunks):
     seen = []
     for r in range(world):
         d = torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r), weights_only=True)
-        assert torch.equal(d['vol'], expect), r                     # every rank holds the whole volume
+        if gather == 'all' or r == world - 1:
+            assert torch.equal(d['vol'], expect), r                 # every rank (or the root alone) holds the whole volume
+        else:
+            assert d['vol'] is None
         seen += [tuple(c) for c in d['calls']]
     seen.sort()                                                    # the pieces tile [0, X) exactly once
     assert seen[0][0] == 0 and seen[-1][1] == res[0]
