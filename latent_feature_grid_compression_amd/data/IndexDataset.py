@@ -40,6 +40,19 @@ class IndexDataset(torch.utils.data.Dataset):
         out[:, :, :, 2] = torch.linspace(float(start[2]), float(end[2]), r[2], dtype=torch.float).view(1, 1, r[2])
         return out
 
+    def tile_positions(self, begin, end) -> torch.Tensor:
+        """(x, y, z, 3) fp32 normalised positions of the voxels [begin, end) of the volume lattice, formed per tile with
+        the arithmetic of the reference's driver (visualization/OutputToVTK.py:23-37): the tile's corner voxels as
+        fractions of the index range -> linspace between them -> [-1, 1] -> axis scales.  (A global lattice differs from
+        this per-tile form by up to 6e-8; the HIP kernel's in-kernel lattice follows the same per-tile form.)"""
+        span = self.max_idx - self.min_idx
+        first = torch.tensor([b / (r - 1) for b, r in zip(begin, self.vol_res_touple)], dtype=torch.float)
+        last = torch.tensor([(e - 1) / (r - 1) for e, r in zip(end, self.vol_res_touple)], dtype=torch.float)
+        lo = (self.min_idx + first * span) / span
+        hi = (self.min_idx + last * span) / span
+        counts = [int(e) - int(b) for b, e in zip(begin, end)]
+        return self.scales.view(1, 1, 1, 3) * (2.0 * self.generate_indices(lo, hi, counts) - 1.0)
+
     def lattice_from_flat(self, flat_idx: torch.Tensor) -> torch.Tensor:
         """Rows of the index table without materialising it."""
         _, Y, Z = self.vol_res_touple

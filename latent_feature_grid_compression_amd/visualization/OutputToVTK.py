@@ -1,8 +1,8 @@
 """Full-volume reconstruction drivers: counterpart of visualization/OutputToVTK.py
 (field_from_net :7-47, calculate_deviation_statistics :53-60, tiled_net_out :64-82).
 
-* ``field_from_net`` keeps the reference's tile loop and call contract (one ``net(tile)`` per 32^3
-  tile) so existing callers work unchanged.
+* ``field_from_net`` keeps the reference's call contract (one ``net(tile)`` per 32^3 tile) so existing
+  callers work unchanged.
 * ``field_from_net_fused`` evaluates an x-slab of the volume in ONE kernel launch: the per-tile lattice
   (same fp32 operation order as the reference's host code) is generated inside the HIP kernel, so no
   positions are uploaded and nothing is copied back per tile.
@@ -23,32 +23,27 @@ import torch.distributed as dist
 from .. import ops
 
 
+def iter_tiles(res, tiled_res: int = 32):
+    """(x0, x1, y0, y1, z0, z1) of every tile of the volume lattice, x-major -- the order slabs and pieces are cut in."""
+    for x0 in range(0, res[0], tiled_res):
+        for y0 in range(0, res[1], tiled_res):
+            for z0 in range(0, res[2], tiled_res):
+                yield (x0, min(x0 + tiled_res, res[0]), y0, min(y0 + tiled_res, res[1]), z0, min(z0 + tiled_res, res[2]))
+
+
 def field_from_net(dataset, net, is_cuda, tiled_res=32, verbose=False):
-    """Reference-compatible tile loop (visualization/OutputToVTK.py:7-47)."""
-    target_res = dataset.vol_res_touple
-    full_vol = torch.zeros(target_res)
-    for xdx in np.arange(0, target_res[0], tiled_res):
-        x_begin, x_end = int(xdx), int(min(xdx + tiled_res, target_res[0]))
-        for ydx in np.arange(0, target_res[1], tiled_res):
-            y_begin, y_end = int(ydx), int(min(ydx + tiled_res, target_res[1]))
-            for zdx in np.arange(0, target_res[2], tiled_res):
-                z_begin, z_end = int(zdx), int(min(zdx + tiled_res, target_res[2]))
-                tile_resolution = torch.tensor([x_end - x_begin, y_end - y_begin, z_end - z_begin], dtype=torch.int)
-                min_alpha_bb = torch.tensor([x_begin / (target_res[0] - 1), y_begin / (target_res[1] - 1),
-                                             z_begin / (target_res[2] - 1)], dtype=torch.float)
-                max_alpha_bb = torch.tensor([(x_end - 1) / (target_res[0] - 1), (y_end - 1) / (target_res[1] - 1),
-                                             (z_end - 1) / (target_res[2] - 1)], dtype=torch.float)
-                min_bounds = dataset.min_idx + min_alpha_bb * (dataset.max_idx - dataset.min_idx)
-                max_bounds = dataset.min_idx + max_alpha_bb * (dataset.max_idx - dataset.min_idx)
-                with torch.no_grad():
-                    start = min_bounds / (dataset.max_idx - dataset.min_idx)
-                    end = max_bounds / (dataset.max_idx - dataset.min_idx)
-                    norm_indices = 2.0 * dataset.generate_indices(start, end, tile_resolution) - 1.0
-                    tile_positions = dataset.scales.view(1, 1, 1, 3) * norm_indices
-                    if is_cuda:
-                        tile_positions = tile_positions.unsqueeze(0).cuda()
-                    tile_vol = net(tile_positions.unsqueeze(0)).squeeze(0).squeeze(-1)
-                    full_vol[x_begin:x_end, y_begin:y_end, z_begin:z_end] = tile_vol.cpu()
+    """One ``net(tile)`` call per tile with the call contract of the reference's driver (visualization/OutputToVTK.py:7-47):
+    a (1, [1,] x, y, z, 3) position tensor in, a clamped (1, [1,] x, y, z, 1) tensor out, result assembled on the host.
+    For callers that hand in their own ``net``; the package's own path is ``field_from_net_fused`` (one launch per slab,
+    positions formed inside the kernel).  Tile positions come from ``IndexDataset.tile_positions``."""
+    res = dataset.vol_res_touple
+    full_vol = torch.zeros(res)
+    with torch.no_grad():
+        for (x0, x1, y0, y1, z0, z1) in iter_tiles(res, tiled_res):
+            pos = dataset.tile_positions((x0, y0, z0), (x1, y1, z1)).unsqueeze(0)
+            if is_cuda:
+                pos = pos.unsqueeze(0).cuda()
+            full_vol[x0:x1, y0:y1, z0:z1] = net(pos).reshape(x1 - x0, y1 - y0, z1 - z0).cpu()
     return full_vol
 
 

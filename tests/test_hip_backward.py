@@ -54,9 +54,19 @@ def test_backward_matches_reference_fixture(dev, name, precision):
     (5, 4, 4, 2, 300),           # NAS lower bounds: 4^3 grid (no wavelet level at all), hidden 4
     (24, 7, 20, 3, 1000),        # one wavelet level, odd grid
 ])
-def test_backward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n):
+@pytest.mark.parametrize('precision', ['f16x2', 'fp32', 'f16'])
+def test_backward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n, precision):
+    """Gradients of every parameter and of the positions against the oracle's autograd, every arithmetic build at every
+    shape: the two full-precision builds at 2e-5 of each tensor's largest entry, the opt-in reduced build ('f16': one f16
+    product per block, the form BASELINE config 3's "bf16 train step" takes here -- DESIGN.md section 7) at its stated
+    bounds: loss 1e-2, gradients 3e-2."""
+    reduced = precision == 'f16'
+    if reduced and (C, G, H, L) not in ((16, 32, 64, 4), (32, 64, 128, 4)):
+        pytest.skip('reduced build: exercised at the BASELINE train-step shapes')
+    tol_loss, tol_grad = (1e-2, 3e-2) if reduced else (1e-5, 2e-5)
     m, sm = build_synth(C, G, H, L, seed=5000 + C + G + H, dev=dev)
     m.train()
+    m.precision = precision
     rng = np.random.default_rng(C * 77 + G)
     # training samples are voxel-lattice points (data/IndexDataset.py:90-96): use a 255^3 lattice
     ds = R.VolumeIndexing((255, 255, 255))
@@ -77,7 +87,7 @@ def test_backward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n):
     yr = R.forward(coeffs, sm['shape_array'], sm['filter_rev'], ws, bs, pos_r, 2, training=True)
     lr = torch.nn.functional.mse_loss(yr.squeeze(-1), target)
     lr.backward()
-    assert abs(loss.item() - lr.item()) <= 1e-5 * abs(lr.item())
+    assert abs(loss.item() - lr.item()) <= tol_loss * abs(lr.item())
     ref = {}
     for i, c in enumerate(coeffs):
         ref['feature_grid.%d' % i] = c.grad.numpy()
@@ -86,8 +96,10 @@ def test_backward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n):
         ref['net_layers.%d.bias' % i] = bs[i].grad.numpy()
     ref['final_layer.weight'] = ws[L].grad.numpy()
     ref['final_layer.bias'] = bs[L].grad.numpy()
-    _grads_vs(m, ref, 2e-5, 'C%d G%d H%d L%d' % (C, G, H, L))
-    assert rel_err(pos_d.grad.cpu().numpy(), pos_r.grad.numpy()) <= 2e-5
+    worst = _grads_vs(m, ref, tol_grad, '%s C%d G%d H%d L%d' % (precision, C, G, H, L))
+    assert rel_err(pos_d.grad.cpu().numpy(), pos_r.grad.numpy()) <= tol_grad
+    if reduced:
+        assert worst > 1e-5                   # really the reduced arithmetic
 
 
 def test_backward_without_input_grad_and_repeatability(dev):
@@ -133,12 +145,39 @@ def test_train_step_matches_reference(dev):
     loss = torch.nn.MSELoss()(pred, gt)
     assert abs(loss.item() - float(g['loss'])) <= 1e-5 * float(g['loss'])
     loss.backward()
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
     opt.step()
-    for k, p in m.state_dict().items():
-        if k.startswith('filter.'):
-            continue
-        # first Adam step moves every entry by lr * g / (|g| + eps): compare to 5 % of lr
-        assert np.abs(p.cpu().numpy() - g['after.' + k]).max() <= 0.05 * 0.008, k
+    # Reference gradients of the same batch (the fixture stores parameters before / after, not gradients): the oracle's
+    # autograd, itself pinned bit-for-bit to the reference's by tests/test_oracle_golden.py.
+    nc = len(m.feature_grid)
+    L = m.num_layer
+    sd = {k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('before.')}
+    leaves = ([sd['feature_grid.%d' % i].clone().requires_grad_(True) for i in range(nc)] +
+              [sd['net_layers.%d.weight' % i].clone().requires_grad_(True) for i in range(L)] + [sd['final_layer.weight'].clone().requires_grad_(True)] +
+              [sd['net_layers.%d.bias' % i].clone().requires_grad_(True) for i in range(L)] + [sd['final_layer.bias'].clone().requires_grad_(True)])
+    yr = R.forward(leaves[:nc], g['shape_array'], sd['filter.filter_rev'], leaves[nc:nc + L + 1], leaves[nc + L + 1:],
+                   torch.from_numpy(g['norm']), 2, training=True)
+    torch.nn.functional.mse_loss(yr.squeeze(-1), torch.from_numpy(g['gt'])).backward()
+    names = (['feature_grid.%d' % i for i in range(nc)] + ['net_layers.%d.weight' % i for i in range(L)] + ['final_layer.weight'] +
+             ['net_layers.%d.bias' % i for i in range(L)] + ['final_layer.bias'])
+    gref = {n: t.grad.numpy() for n, t in zip(names, leaves)}
+    lr, eps = 0.008, 1e-8
+    checked = 0
+    for k, p in m.named_parameters():
+        upd = (p.detach() - before[k]).cpu().numpy().astype(np.float64)
+        upd_ref = (g['after.' + k].astype(np.float64) - g['before.' + k].astype(np.float64))
+        gr = np.abs(gref[k])
+        # Adam's first step moves an entry by -lr g / (|g| + eps).  Entries whose reference gradient is neither tiny
+        # against its tensor (> 1e-6 of the largest: their sign cannot flip under the 2e-5 gradient tolerance ... if it is
+        # also > 1e-4 of it) nor comparable to eps are compared at 1e-3 RELATIVE; the rest -- sign-flip-prone, listed
+        # here, not hidden under a blanket tolerance -- only have to stay inside the step's bound lr.
+        solid = (gr > 1e-4 * gr.max()) & (gr > 1e3 * eps)
+        # (a small batch leaves most coefficient gradients exactly zero: no per-tensor quota, the total is asserted below)
+        if solid.any():
+            assert np.abs(upd[solid] - upd_ref[solid]).max() <= 1e-3 * np.abs(upd_ref[solid]).min(), k
+        assert np.abs(upd).max() <= lr * (1 + 1e-3) and np.abs(upd - upd_ref)[~solid].max(initial=0.0) <= 2 * lr, k
+        checked += int(solid.sum())
+    assert checked > 1000
 
 
 def test_device_lattice_sampler_matches_index_dataset(dev):

@@ -600,3 +600,42 @@ def test_non_current_device_is_respected(dev):
     from latent_feature_grid_compression_amd import _lib
     with pytest.raises(_lib.LfgcError, match='different devices'):
         m(pos.to(dev))
+
+
+def test_cfg4_volume_255_cubed_sharded_edge_tiles(dev):
+    """BASELINE config 4 itself: the 255^3 volume (7 x 32 + 31 per axis: ragged last tile on every axis) with the cfg 3/4
+    model, through the sharded driver's collective path on one rank (RCCL, world 1, always_gather), both assembly modes.
+    The three 31-wide edge tiles (one per axis) and the 31^3 corner tile are checked against the oracle's per-tile forward
+    at 1e-5; the whole volume against the package's per-tile driver."""
+    import torch.distributed as dist
+    from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
+    from latent_feature_grid_compression_amd.visualization import OutputToVTK as V
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29617')
+    m, sm = build_synth(32, 64, 128, 4, seed=4242, dev=dev)
+    m.eval()
+    res = (255, 255, 255)
+    ds = IndexDataset(res, 16, build_index_table=False)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        tm = {}
+        vol = V.reconstruct_volume_sharded(ds, m, chunks=4, always_gather=True, gather='root', timings=tm)
+        vol_all = V.reconstruct_volume_sharded(ds, m, chunks=3, always_gather=True, gather='all')
+    finally:
+        dist.destroy_process_group()
+    assert tuple(vol.shape) == res and tm['world_size'] == 1 and tm['gather'] == 'root' and tm['compute_ms'] > 0
+    assert torch.equal(vol, vol_all)
+    dense = R.decode_volume(sm['coeffs'], sm['shape_array'], sm['filter_rev'])
+    ro = R.VolumeIndexing(res)
+    scale = None
+    for box in [(224, 255, 0, 32, 0, 32), (0, 32, 224, 255, 32, 64), (96, 128, 64, 96, 224, 255), (224, 255, 224, 255, 224, 255),
+                (0, 32, 0, 32, 0, 32)]:
+        pos = R.tile_positions(ro, box).reshape(-1, 3)
+        yr = R.forward_from_grid(dense, sm['weights'], sm['biases'], pos, 2).clamp(-1, 1).reshape(box[1] - box[0], box[3] - box[2], box[5] - box[4])
+        mine = vol[box[0]:box[1], box[2]:box[3], box[4]:box[5]].cpu()
+        scale = float(yr.abs().max()) if scale is None else max(scale, float(yr.abs().max()))
+        assert float((mine - yr).abs().max()) <= 1e-5 * scale, box
+    # size-independent property at the full size: the one-launch-per-slab path equals the per-tile call contract
+    sub = V.field_from_net(IndexDataset((31, 40, 33), 16, build_index_table=False), m, is_cuda=True)
+    one = V.field_from_net_fused(IndexDataset((31, 40, 33), 16, build_index_table=False), m).cpu()
+    assert float((sub - one).abs().max()) <= 2e-6
