@@ -278,7 +278,7 @@ typedef struct lfgc_positions {
  *             pre-activation are saved for lfgc_backward_f32 (private layout).
  *   status    device int32 or NULL (ignored by LFGC_PRECISION_F32).  The reference computes in fp32 and stays finite
  *             for any finite parameters (model/Feature_Grid_Model.py:12-13, :72-75); the f16 builds have a range.
- *             With status != NULL the call clears *status, the f16 kernel sets it to 1 if any sample left that range,
+ *             With status != NULL the call clears *status (a one-thread kernel), the f16 kernel sets it to 1 if any sample left that range,
  *             and the call then enqueues the same pass on the exact-fp32 build predicated on *status (its workgroups
  *             return immediately when it is 0): `out` (and `stash`) always hold reference-equivalent results, without
  *             a host synchronisation.  With status == NULL out-of-range samples are returned as NaN. */

@@ -17,6 +17,10 @@ unsigned long long* g_stamps = nullptr;
 #endif
 }  // namespace
 
+__global__ void lfgc_clear_word_kernel(int32_t* w) {
+    if (threadIdx.x == 0) __hip_atomic_store(w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 #ifdef LFGC_STAMPS
 // Diagnostics builds only (tools/phase_stamps.py): device buffer of 16 counters per wave slot (grid x 8 waves).
 extern "C" void lfgc_debug_set_stamp_buffer(void* p) { g_stamps = reinterpret_cast<unsigned long long*>(p); }
@@ -94,9 +98,13 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     if (grid > a.nbatches) grid = a.nbatches;
     hipStream_t st = (hipStream_t)stream;
     if (h16) {
-        if (status) {                                   // range screen on: cleared here, set by the kernel (stream order)
-            const hipError_t e = hipMemsetAsync(status, 0, sizeof(int32_t), st);
-            if (e != hipSuccess) return (int)e;
+        if (status) {
+            // range screen on: cleared here, set by the kernel, read by the predicated redo -- all in stream order.
+            // Cleared by a kernel of our own, NOT hipMemsetAsync: inside a captured HIP graph (ROCm 7.2) the memset
+            // node of a 4-byte clear did not take effect before the following kernel nodes on replay -- the redo then
+            // ran in full on every replay of a captured train step (measured: 58 us instead of 4 us; profiles/r2).
+            hipLaunchKernelGGL(lfgc_clear_word_kernel, dim3(1), dim3(64), 0, st, status);
+            LFGC_HIP_CHECK_LAUNCH();
             a.status = status;
         }
         int rc16;

@@ -305,7 +305,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd_kernel(const LfgcFwdAr
     constexpr int EPH = EP / 2;          // scalar inputs carried per lane
     constexpr int NT = WAVES * 64;
 
-    if (a.redo_if && *a.redo_if == 0) return;            // range fallback of the f16 builds: nothing to redo (uniform)
+    // range fallback of the f16 builds: nothing to redo (uniform).  Device-scope load: the word is written by the kernel
+    // enqueued just before this one (and cleared by a memset before that), possibly through another XCD's L2
+    if (a.redo_if && __hip_atomic_load(a.redo_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_final = smem;               // Wf (HP) | bf (4)

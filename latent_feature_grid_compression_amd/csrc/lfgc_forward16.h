@@ -465,7 +465,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
         // as a finite wrong number.
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         if (!(tmax <= LFGC_TURNS_MAX)) y = __builtin_nanf("");
-        if (a.status && valid && !(__builtin_fabsf(y) < __builtin_inff())) *a.status = 1;
+        if (a.status && valid && !(__builtin_fabsf(y) < __builtin_inff()))
+            __hip_atomic_store(a.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.clamp) y = fminf(fmaxf(y, -1.0f), 1.0f);
         if (valid && hh == 0) a.out[n] = y;
     }
