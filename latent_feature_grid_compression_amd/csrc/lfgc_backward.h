@@ -29,6 +29,7 @@ struct LfgcBwdArgs {
     const float* stash;
     const float* d_out;        // (N)
     float* dstash;             // [tiles][L*16*MT][64]
+    float* dscale;             // [tiles][L]: the power-of-two scale each tile's dA_l was split with (f16 builds), for the weight kernel
     float* d_grid;             // (D,H,W,Cs), accumulated with float atomics
     float* d_pos;              // (N,3) or nullptr
     long long nbatches;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 h16x8 Fhi[2 * MT], Flo[2 * MT];
                 float isc;
                 const float sc = lfgc_tile_pow2_scale<16 * MT>(dA, isc);
+                if (lane == 0) a.dscale[tile_idx * L + l] = sc;
                 lfgc_split_scaled<2 * MT, SPLIT>(dA, sc, Fhi, Flo);
                 const float* s_row = acquire(l) + j * ST + 8 * hh;
                 const float is = s_inv[l] * isc;
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             float isc = 1.0f;
             if (H16) {
                 const float sc = lfgc_tile_pow2_scale<16 * MT>(dA, isc);
+                if (lane == 0) a.dscale[tile_idx * L] = sc;
                 lfgc_split_scaled<2 * MT, SPLIT>(dA, sc, Fhi, Flo);
             }
             const float* s_row = acquire(0) + j * ST + (H16 ? 8 : 4) * hh;
@@ -408,6 +411,7 @@ struct LfgcWgradArgs {
     int L;
     float* slabs;              // [gridDim.x][slab_floats]
     int slab_floats;
+    const float* dscale;       // [tiles][L] from the data kernel, or nullptr: exact f32 MFMA contraction
 };
 
 // Slab layout (floats): per hidden layer l: dW [HP][NC_l] (NC_0 = K0R in packed column order, else HP) | db [HP];
@@ -417,11 +421,13 @@ __host__ __device__ inline int lfgc_slab_layer_off(const LfgcPlan& p, int l) {
 }
 __host__ __device__ inline int lfgc_slab_floats(const LfgcPlan& p) { return lfgc_slab_layer_off(p, p.L) + p.HP + 4; }
 
-// 16 consecutive samples (16*kk .. 16*kk+15) of stash row `row16` (= (m*16 + r)*64 + hh*32) -> v[16]
-__device__ __forceinline__ void lfgc_load16(const float* __restrict__ base, float (&v)[16]) {
+// The 16 samples a lane contributes to a tile's contraction: [8 kh, 8 kh + 8) and [16 + 8 kh, 16 + 8 kh + 8) of stash row
+// `base` (= row start + lane-half offset): exactly the k values lane half kh feeds to the two 16-deep k-steps of
+// v_mfma_f32_32x32x16_f16 (and, pairwise with the other half, to 16 v_mfma_f32_32x32x2_f32).
+__device__ __forceinline__ void lfgc_load16(const float* __restrict__ base, int kh, float (&v)[16]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(base + 4 * q);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(base + 8 * kh + 16 * (q >> 1) + 4 * (q & 1));
         v[4 * q + 0] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
     }
 }
@@ -431,6 +437,11 @@ __device__ __forceinline__ void lfgc_load16(const float* __restrict__ base, floa
 // The workgroup has 8 waves: waves 0-3 and 4-7 run the same tile/column assignment on alternate sample tiles (two
 // waves per SIMD, so one wave's loads hide under the other's MFMAs); the second half hands its accumulators over
 // through LDS (`s_comb`, [4 waves][TPW*17][64]) and the first half writes the slab.
+// Contraction over the 32 samples of a tile: with a.dscale (the f16 builds) as f16 hi/lo split operands, three
+// v_mfma_f32_32x32x16_f16 per 16 samples with fp32 accumulation -- dA scaled by the power of two the data kernel chose for
+// the tile, the tile's product scaled back exactly before it joins the running sum --, 192 instead of 1024 matrix-pipe
+// cycles per 32x32 output tile; a tile whose inputs leave the f16 range (|H| >= 65504: a diverged model), and the exact
+// build, take sixteen v_mfma_f32_32x32x2_f32 (bitwise an fp32 fmaf chain).
 template <int MT, int NT, bool LAYER0, int KS0>
 __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, float* __restrict__ slab_l, int ncol,
                                                  int k0p, long long per_tile, long long dper_tile,
@@ -455,18 +466,18 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
     if (LAYER0) {
         const int s = 4 * (col >> 3) + (col & 3), hb = (col >> 2) & 1;
         bvalid = col < k0p;
-        boff = (long long)(bvalid ? s : 0) * 64 + hb * 32 + 16 * kk;
+        boff = (long long)(bvalid ? s : 0) * 64 + hb * 32;
     } else {
         const int r = (i & 3) + 4 * (i >> 3), hb = (i >> 2) & 1;
-        boff = 64LL * KS0 + (long long)(l - 1) * (64 * 16 * MT) + (long long)(n_t * 16 + r) * 64 + hb * 32 + 16 * kk;
+        boff = 64LL * KS0 + (long long)(l - 1) * (64 * 16 * MT) + (long long)(n_t * 16 + r) * 64 + hb * 32;
     }
     // A operand rows: row = 32 m + i of dA_l
     const int ra = (i & 3) + 4 * (i >> 3), ha = (i >> 2) & 1;
-    const long long aoff_base = (long long)l * (64 * 16 * MT) + (long long)ra * 64 + ha * 32 + 16 * kk;
+    const long long aoff_base = (long long)l * (64 * 16 * MT) + (long long)ra * 64 + ha * 32;
 
     for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
         float Bv[16];
-        lfgc_load16(a.stash + t * per_tile + boff, Bv);
+        lfgc_load16(a.stash + t * per_tile + boff, kk, Bv);
         if (LAYER0) {
             if (!bvalid) {
 #pragma unroll
@@ -486,16 +497,49 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
 #pragma unroll
             for (int s = 0; s < 16; ++s) Bv[s] = Hv[s];
         }
+        bool split = a.dscale != nullptr;
+        float sc = 1.0f, isc = 1.0f;
+        h16x8 Bhi[2], Blo[2];
+        if (split) {
+            float bmax = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; s += 2) bmax = lfgc_absmax3(bmax, Bv[s], Bv[s + 1]);
+            split = !__any(!(bmax < 65504.0f));                    // wave-uniform; NaN / inf / huge inputs -> exact path
+            sc = a.dscale[t * a.L + l];
+            isc = __int_as_float(0x7F000000 - __float_as_int(sc));  // 1 / 2^k, exact
+            lfgc_split8(Bv, Bhi[0], Blo[0]);
+            lfgc_split8(Bv + 8, Bhi[1], Blo[1]);
+        }
 #pragma unroll
         for (int tw = 0; tw < TPW; ++tw) {
             const int m = msub + tw * WPN;
             if (m < MT) {
                 float Av[16];
-                lfgc_load16(a.dstash + t * dper_tile + aoff_base + (long long)m * (16 * 64), Av);
+                lfgc_load16(a.dstash + t * dper_tile + aoff_base + (long long)m * (16 * 64), kk, Av);
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    acc[tw] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[s], Bv[s], acc[tw], 0, 0, 0);
-                    dbp[tw] += Av[s];
+                for (int s = 0; s < 16; ++s) dbp[tw] += Av[s];
+                if (split) {
+                    float As[16];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) As[s] = Av[s] * sc;
+                    h16x8 Ahi[2], Alo[2];
+                    lfgc_split8(As, Ahi[0], Alo[0]);
+                    lfgc_split8(As + 8, Ahi[1], Alo[1]);
+                    f32x16 tmp;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) tmp[r] = 0.0f;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        tmp = __builtin_amdgcn_mfma_f32_32x32x16_f16(Alo[ks], Bhi[ks], tmp, 0, 0, 0);
+                        tmp = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[ks], Blo[ks], tmp, 0, 0, 0);
+                        tmp = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ahi[ks], Bhi[ks], tmp, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tw][r] = __builtin_fmaf(tmp[r], isc, acc[tw][r]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        acc[tw] = __builtin_amdgcn_mfma_f32_32x32x2f32(Av[s], Bv[s], acc[tw], 0, 0, 0);
                 }
             }
         }
@@ -568,10 +612,10 @@ __global__ __launch_bounds__(512, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
         float wsum = 0.0f, bsum = 0.0f;
         if (w4 < MT) {
             const int r = (i & 3) + 4 * (i >> 3), hb = (i >> 2) & 1;
-            const long long boff = 64LL * KS0 + (long long)(L - 1) * (64 * 16 * MT) + (long long)(w4 * 16 + r) * 64 + hb * 32 + 16 * kk;
+            const long long boff = 64LL * KS0 + (long long)(L - 1) * (64 * 16 * MT) + (long long)(w4 * 16 + r) * 64 + hb * 32;
             for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
                 float Bv[16];
-                lfgc_load16(a.stash + t * per_tile + boff, Bv);
+                lfgc_load16(a.stash + t * per_tile + boff, kk, Bv);
                 bool bad = false;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) bad |= lfgc_trig_out_of_range(Bv[s]);
@@ -584,7 +628,7 @@ __global__ __launch_bounds__(512, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
                 }
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const long long smp = t * 32 + 16 * kk + s;
+                    const long long smp = t * 32 + 8 * kk + 16 * (s >> 3) + (s & 7);       // lfgc_load16's sample order
                     const float dyv = smp < a.n ? a.d_out[smp] : 0.0f;
                     wsum = __builtin_fmaf(dyv, Hv[s], wsum);
                     bsum += dyv;

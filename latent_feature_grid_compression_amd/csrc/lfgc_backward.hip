@@ -12,7 +12,7 @@ const int kMaxSlabs = 256;          // workgroups of the weight-gradient kernel 
 struct Carve {
     long long ntiles, nbatches;
     int nslabs;
-    long long dstash_floats, slab_floats_total;
+    long long dstash_floats, slab_floats_total, dscale_floats;
 };
 
 Carve carve(const LfgcPlan& p, long long n) {
@@ -23,6 +23,7 @@ Carve carve(const LfgcPlan& p, long long n) {
     if (c.nslabs < 1) c.nslabs = 1;
     c.dstash_floats = c.ntiles * 64LL * (p.L * 16 * p.MT);
     c.slab_floats_total = (long long)c.nslabs * lfgc_slab_floats(p);
+    c.dscale_floats = (c.ntiles * p.L + 3) / 4 * 4;     // one power-of-two scale per (tile, layer), f16 builds
     return c;
 }
 }  // namespace
@@ -32,7 +33,7 @@ extern "C" int64_t lfgc_backward_workspace_bytes(const lfgc_mlp_desc* desc, int6
     if (n_samples < 0) return LFGC_E_SHAPE;
     const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
     const Carve c = carve(p, n_samples);
-    return (c.dstash_floats + c.slab_floats_total) * 4;
+    return (c.dstash_floats + c.slab_floats_total + c.dscale_floats) * 4;
 }
 
 extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
@@ -65,19 +66,21 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
         return LFGC_OK;
     }
     const Carve c = carve(p, n);
-    if (!workspace || workspace_bytes < (c.dstash_floats + c.slab_floats_total) * 4) return LFGC_E_WORKSPACE;
+    if (!workspace || workspace_bytes < (c.dstash_floats + c.slab_floats_total + c.dscale_floats) * 4) return LFGC_E_WORKSPACE;
     float* dstash = reinterpret_cast<float*>(workspace);
     float* slabs = dstash + c.dstash_floats;
+    float* dscale = slabs + c.slab_floats_total;
 
     LfgcBwdArgs a;
     a.pos = positions->pos; a.n = n;
     a.grid = grid_cl; a.D = D; a.H = H; a.W = W; a.Cs = p.CH;
     a.packed = packed; a.L = p.L; a.stash = stash; a.d_out = d_out;
-    a.dstash = dstash; a.d_grid = d_grid_cl; a.d_pos = d_pos;
+    a.dstash = dstash; a.dscale = dscale; a.d_grid = d_grid_cl; a.d_pos = d_pos;
 
     LfgcWgradArgs w;
     w.stash = stash; w.dstash = dstash; w.d_out = d_out; w.n = n; w.ntiles = c.ntiles; w.L = p.L;
     w.slabs = slabs; w.slab_floats = lfgc_slab_floats(p);
+    w.dscale = precision == LFGC_PRECISION_F32 ? nullptr : dscale;     // f16 builds: f16-split contraction (lfgc_backward.h)
 
     const int cus = lfgc_num_cus();       // per device
     // data kernel: one workgroup per CU, 8 waves once every CU gets a 256-sample batch, else 4 (tiles beyond the

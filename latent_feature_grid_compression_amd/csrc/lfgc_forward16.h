@@ -334,6 +334,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             for (int i = tid; i < (BLK0 + (L - 1) * BLK1) / 4; i += NT) reinterpret_cast<f32x4*>(s_w)[i] = srcw[i];
         } else {
             lfgc_dma_to_lds(hblk, s_w, BLK0, wave, lane, WAVES);
+#if LFGC_ABLATE & 8             // diagnostics: both ring slots hold layer 1's block for good (finite data, wrong results)
+            lfgc_dma_to_lds(hblk + BLK0, s_w, BLK1, wave, lane, WAVES);
+            lfgc_dma_to_lds(hblk + BLK0, s_w + BLKMAX, BLK1, wave, lane, WAVES);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         }
     }
     if (!a.pos && a.coord_table) {

@@ -2,21 +2,46 @@
 signature, computed by a HIP kernel that follows the reference's operation order bit for bit."""
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .. import ops
 
 
+_HOST_BOUNDS = {}       # (data_ptr, device, in-place version) of a bounds tensor -> (weakref to it, its 3 values as host floats)
+
+
+def _host3(v):
+    """The three values of a bounds argument as host floats.  The reference's training loop passes these as DEVICE
+    tensors on every step (training/training.py:107-109): reading them back each time would be a blocking copy per
+    argument per step (and would make the step impossible to capture in a HIP graph), so the values of a given tensor
+    (same storage, same in-place version) are read once and remembered."""
+    if not torch.is_tensor(v):
+        return [float(x) for x in v]
+    if not v.is_cuda:
+        return v.detach().tolist()
+    key = (v.data_ptr(), v.device.index, v._version)
+    ent = _HOST_BOUNDS.get(key)
+    if ent is not None and ent[0]() is v:
+        return ent[1]
+    vals = v.detach().cpu().tolist()
+    if len(_HOST_BOUNDS) > 64:
+        for k in [k for k, e in _HOST_BOUNDS.items() if e[0]() is None]:
+            del _HOST_BOUNDS[k]
+    _HOST_BOUNDS[key] = (weakref.ref(v), vals)
+    return vals
+
+
 def trilinear_f_interpolation(p, f, min_bb, max_bb, res):
     """p (N,3) raw lattice positions, f (X,Y,Z) volume, min_bb/max_bb/res (3,) float tensors -> (N,)."""
-    return ops.gt_interp(p, f, min_bb.detach().cpu(), max_bb.detach().cpu(), res.detach().cpu())
+    return ops.gt_interp(p, f, _host3(min_bb), _host3(max_bb), _host3(res))
 
 
 def trilinear_mse_loss(pred, p, f, min_bb, max_bb, res):
     """``torch.nn.MSELoss()(pred, trilinear_f_interpolation(p, f, min_bb, max_bb, res))`` (training/training.py:107-109,
     :127) as one fused HIP pass: same ground truth bit for bit, fp64-accumulated mean, analytic gradient to ``pred``."""
-    host = lambda v: v.detach().cpu().tolist() if torch.is_tensor(v) else list(v)
-    return ops.gt_mse_loss(pred, p, f, host(min_bb), host(max_bb), host(res))
+    return ops.gt_mse_loss(pred, p, f, _host3(min_bb), _host3(max_bb), _host3(res))
 
 
 def finite_difference_trilinear_grad(p, f, min_bb, max_bb, res, scale=None):

@@ -70,6 +70,8 @@ class Feature_Grid_Model(nn.Module):
         self._grid_cache = None      # (key, channel-last dense grid) while parameters are unchanged (eval)
         self._pack_cache = None      # (key, packed MLP blob)
         self._penalty_cache = None   # penalty sums taken inside the last differentiable fused decode
+        self._penalty_wanted = False  # set by the first pruning loss that asks for them (cached_penalties)
+        self._decode_count = 0       # part of the cache key: optimizers may change parameters without bumping versions
         self._desc = None
 
     # ---- caches -------------------------------------------------------------------------------------------
@@ -139,8 +141,11 @@ class Feature_Grid_Model(nn.Module):
         """(sum of squared coefficients per tensor (n,), {drop-layer index: its L1 term}) from the last differentiable
         decode, with their gradients riding in that decode's backward kernels -- or None if no decode has run since a
         parameter last changed (the pruning losses then evaluate the terms with a launch of their own)."""
+        # the sums are only produced once a loss has shown that it consumes them: the fine-tune phase of the reference
+        # (training/training.py:236: drop_loss=None with the mask layers still installed) then pays no penalty launch
+        self._penalty_wanted = True
         c, self._penalty_cache = self._penalty_cache, None      # consumed once: see _decode on why no reference is kept
-        if c is None or c['key'] != self._penalty_key() or not torch.is_grad_enabled():
+        if c is None or c['key'] != self._penalty_key() or c['decode'] != self._decode_count or not torch.is_grad_enabled():
             return None
         n = c['n']
         l1 = {i: c['pen'][n + j] for j, i in enumerate(c['l1_idx'])}
@@ -149,6 +154,7 @@ class Feature_Grid_Model(nn.Module):
     def _decode(self, channel_last: bool) -> torch.Tensor:
         coeffs, factors, thresholds, l1_flags = self._dropped()
         self._penalty_cache = None
+        self._decode_count += 1
         fused = any(f is not None for f in factors)
         if fused and len(coeffs) == 1:                     # no wavelet level at all: the layer is all there is
             coeffs = [ops.DropApplyFn.apply(coeffs[0], factors[0], thresholds[0])]
@@ -160,7 +166,7 @@ class Feature_Grid_Model(nn.Module):
                 # out of the same node, so that their gradients ride in its adjoint kernels (SmallifyLoss /
                 # VariationalDropoutLoss pick them up through cached_penalties())
                 n = len(coeffs)
-                if os.environ.get('LFGC_NO_PENALTY_FOLD'):       # diagnostics (tools/microbench/penalty_fold_ab.py)
+                if os.environ.get('LFGC_NO_PENALTY_FOLD') or not self._penalty_wanted:   # env: diagnostics (tools/microbench/penalty_fold_ab.py)
                     return ops.DecodeVolumeDropFn.apply(self.filter.filter_rev, self.shape_array, channel_last, thresholds,
                                                         n, *[c.contiguous() for c in coeffs], *factors)
                 # NOTE the cache below is handed out ONCE (cached_penalties pops it): a reference to `pen` that outlives
@@ -169,7 +175,7 @@ class Feature_Grid_Model(nn.Module):
                 grid, pen = ops.DecodeVolumePenaltyFn.apply(self.filter.filter_rev, self.shape_array, channel_last,
                                                             thresholds, n, l1_flags,
                                                             *[c.contiguous() for c in coeffs], *factors)
-                self._penalty_cache = {'key': self._penalty_key(), 'pen': pen, 'n': n,
+                self._penalty_cache = {'key': self._penalty_key(), 'decode': self._decode_count, 'pen': pen, 'n': n,
                                        'l1_idx': [i for i in range(n) if l1_flags[i] and factors[i] is not None]}
                 return grid
             return ops.decode_levels_drop([c.detach() for c in coeffs], [None if f is None else f.detach() for f in factors],
