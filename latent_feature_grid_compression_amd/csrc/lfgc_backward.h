@@ -167,7 +167,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
     constexpr int K0P16 = (K0P + 15) / 16 * 16;
     constexpr int HBLK0 = HP * (K0P16 + 4) + HP, HBLK1 = HP * (HP + 4) + HP;
     const int off_h = off_t + TB0 + (L - 1) * TB1;            // scales, then the f16-split forward blocks (lfgc_common.h)
-    const int off_img = H16 ? off_h + 32 + LFGC_MAX_LAYERS * HP + HBLK0 + (L - 1) * HBLK1 : off_t;
+    const int off_img = H16 ? off_h + 32 + LFGC_MAX_LAYERS * HP + HP + HBLK0 + (L - 1) * HBLK1 : off_t;
     auto image_src = [&](int l) -> const float* {
         return l == 0 ? a.packed + off_img : a.packed + off_img + TB0 + (long long)(l - 1) * TB1;
     };

@@ -7,7 +7,10 @@ int lfgc_bwd_dispatch_ch24(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, i
 int lfgc_bwd_dispatch_ch32(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
 
 namespace {
-const int kMaxSlabs = 256;          // workgroups of the weight-gradient kernel (one partial slab each)
+#ifndef LFGC_MAX_SLABS
+#define LFGC_MAX_SLABS 256
+#endif
+const int kMaxSlabs = LFGC_MAX_SLABS;   // workgroups of the weight-gradient kernel (one partial slab each)
 
 struct Carve {
     long long ntiles, nbatches;

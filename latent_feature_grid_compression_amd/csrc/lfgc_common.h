@@ -45,7 +45,7 @@ struct LfgcPlan {
     // f16-split forward section (lfgc_forward16.h): per-layer power-of-two scales, then layer blocks whose rows
     // hold, per 16-column k-step, [lane half 0: 8 hi halfs | 8 lo halfs][lane half 1: 8 hi | 8 lo] (64 B), i.e.
     // 4 bytes per weight like the fp32 blocks, same +16 B row padding, followed by the scaled fp32 bias.
-    int K0P16, SH0, SH1, blkh0, blkh1, off_h, off_hbias, off_hblk;
+    int K0P16, SH0, SH1, blkh0, blkh1, off_h, off_hbias, off_hwf, off_hblk;
     int off_ht;              // f16-split TRANSPOSED images for the backward data chain (same sizes as tblk0 / tblk1)
 };
 
@@ -81,10 +81,12 @@ __host__ __device__ inline LfgcPlan lfgc_make_plan(int C, int H, int L, int NF) 
     p.blkh1 = p.HP * p.SH1 + p.HP;
     // 32 floats: scale[8] | 1/scale[8] of the transposed images (true W), then scale[8] | 1/scale[8] of the forward
     // images (W / pi [/ LFGC_ACT_SCALE], lfgc_forward16.h); then the hidden-layer biases divided by pi, un-scaled,
-    // LFGC_MAX_LAYERS x HP (the f16-split forward adds them in its epilogue and keeps them LDS-resident)
+    // LFGC_MAX_LAYERS x HP (the f16-split forward adds them in its epilogue and keeps them LDS-resident); then the head's
+    // weights divided by LFGC_ACT_SCALE (the last hidden layer hands its activations over scaled like every other)
     p.off_h = p.off_t + p.tblk0 + (L - 1) * p.tblk1;
     p.off_hbias = p.off_h + 32;
-    p.off_hblk = p.off_hbias + LFGC_MAX_LAYERS * p.HP;
+    p.off_hwf = p.off_hbias + LFGC_MAX_LAYERS * p.HP;        // head weights divided by LFGC_ACT_SCALE: HP floats
+    p.off_hblk = p.off_hwf + p.HP;
     p.off_ht = p.off_hblk + p.blkh0 + (L - 1) * p.blkh1;
     p.total_floats = p.off_ht + p.tblk0 + (L - 1) * p.tblk1;
     p.stash_tile_floats = 64 * (p.KS0 + L * 16 * p.MT);
@@ -197,6 +199,13 @@ __device__ __forceinline__ float lfgc_sinf_t(float x) {
     float sb;
     const float r = WIDE ? lfgc_reduce_pi_wide(x, sb) : lfgc_reduce_pi_fast(x, sb);
     return __int_as_float(__float_as_int(lfgc_sin_poly(r)) ^ __float_as_int(sb));
+}
+
+template <bool WIDE>
+__device__ __forceinline__ float lfgc_cosf_t(float x) {
+    float sb;
+    const float r = WIDE ? lfgc_reduce_pi_wide(x, sb) : lfgc_reduce_pi_fast(x, sb);
+    return __int_as_float(__float_as_int(lfgc_cos_poly(r)) ^ __float_as_int(sb));
 }
 
 template <bool WIDE>

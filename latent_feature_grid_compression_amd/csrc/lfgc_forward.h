@@ -163,8 +163,32 @@ struct LfgcSampler {
     }
 
     __device__ __forceinline__ void finish(int hh, float (&B0)[CHH + EPH]) {
-        // ---- scalar inputs [p | sin f_k p | cos f_k p]: every lane evaluates all, keeps its half -----
-        {
+        // ---- scalar inputs [p | sin f_k p | cos f_k p]: a lane keeps only its half of the list ---------------------
+        if constexpr (NF == 2) {
+            // e = [p0 p1 p2 s0x s0y s0z c0x c0y | c0z s1x s1y s1z c1x c1y c1z 0] (f0, f1 = 2 f0): lane half 0 needs sin/cos
+            // of f0 p, lane half 1 those of f1 p plus cos(f0 p2) -- three sincos of lane-half-dependent arguments and one
+            // cosine instead of six sincos per lane.  Arguments are formed as before (one fp32 product each).
+            const float f0 = lfgc_freq(0), f1 = lfgc_freq(1);
+            const float f = hh ? f1 : f0;
+            const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f), a3 = __fmul_rn(p2, f0);
+            const bool bad = lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2) |
+                             lfgc_trig_out_of_range(a3);
+            float sA, cA, sB, cB, sC, cC, sD, cD;
+            lfgc_sincosf_t<false>(a0, sA, cA);
+            lfgc_sincosf_t<false>(a1, sB, cB);
+            lfgc_sincosf_t<false>(a2, sC, cC);
+            cD = lfgc_cosf_t<false>(a3);
+            if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
+                lfgc_sincosf_t<true>(a0, sA, cA);
+                lfgc_sincosf_t<true>(a1, sB, cB);
+                lfgc_sincosf_t<true>(a2, sC, cC);
+                lfgc_sincosf_t<true>(a3, sD, cD);
+            }
+            const float lo[8] = {p0, p1, p2, sA, sB, sC, cA, cB};
+            const float hi[8] = {cD, sA, sB, sC, cA, cB, cC, 0.0f};
+#pragma unroll
+            for (int t = 0; t < EPH; ++t) B0[CHH + t] = hh ? hi[t] : lo[t];
+        } else {
             float e[EP];
             e[0] = p0; e[1] = p1; e[2] = p2;
             bool bad = false;

@@ -124,20 +124,13 @@ struct LfgcEpilogue {
             if (LAST) tmax = lfgc_absmax3(tmax, t0, t1);
         } else if constexpr (S == 1) {
             c1 = __builtin_amdgcn_cosf(t1);
-            if (LAST) {       // unscaled result for the fp32 head: pi/2 as a two-term constant
-                const float e0 = __builtin_fmaf(t0, -4.371138828673793e-08f, __builtin_fmaf(c0, -0.5f, 0.5f));
-                h0 = __builtin_fmaf(t0, 1.5707963705062866f, e0);
-            } else {
-                h0 = __builtin_fmaf(t0, LFGC_ACT_C, __builtin_fmaf(c0, -LFGC_ACT_HALF, LFGC_ACT_HALF));
-            }
+            h0 = __builtin_fmaf(t0, LFGC_ACT_C, __builtin_fmaf(c0, -LFGC_ACT_HALF, LFGC_ACT_HALF));     // scaled, also for the head
         } else {
-            if (LAST) {
-                const float e = __builtin_fmaf(t1, -4.371138828673793e-08f, __builtin_fmaf(c1, -0.5f, 0.5f));
-                h1 = __builtin_fmaf(t1, 1.5707963705062866f, e);
+            h1 = __builtin_fmaf(t1, LFGC_ACT_C, __builtin_fmaf(c1, -LFGC_ACT_HALF, LFGC_ACT_HALF));
+            if (LAST) {       // fp32 head on the scaled activations (its weights carry 1 / LFGC_ACT_SCALE)
                 ydot = __builtin_fmaf(wq[Q & 1][I], h0, ydot);
                 ydot = __builtin_fmaf(wq[Q & 1][I + 1], h1, ydot);
             } else {
-                h1 = __builtin_fmaf(t1, LFGC_ACT_C, __builtin_fmaf(c1, -LFGC_ACT_HALF, LFGC_ACT_HALF));
                 const unsigned hp = lfgc_cvt_pk(h0, h1);
                 Ohi[P >> 2][P & 3] = hp;
                 if (SPLIT) Olo[P >> 2][P & 3] = lfgc_lo_pk(hp, h0, h1);
@@ -322,11 +315,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     const int L = a.L;
     const int off_final = F_BLK0 + (L - 1) * F_BLK1;
     const int off_h = off_final + HP + 4 + K0R * (HP + 4) + (L - 1) * HP * (HP + 4);
-    const float* hblk = a.packed + off_h + 32 + LFGC_MAX_LAYERS * HP;
+    const float* hblk = a.packed + off_h + 32 + LFGC_MAX_LAYERS * HP + HP;
 
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.packed + off_final);
-        for (int i = tid; i < (HP + 4) / 4; i += NT) reinterpret_cast<f32x4*>(s_final)[i] = src[i];
+        // head: weights divided by LFGC_ACT_SCALE (the last hidden layer's activations arrive scaled), bias as it is
+        for (int i = tid; i < HP; i += NT) s_final[i] = a.packed[off_h + 32 + LFGC_MAX_LAYERS * HP + i];
+        if (tid < 4) s_final[HP + tid] = a.packed[off_final + HP + tid];
         if (tid < 16) s_scale[tid] = a.packed[off_h + 16 + tid];       // the forward images' own scales
         for (int i = tid; i < L * HP; i += NT) s_bias[i] = a.packed[off_h + 32 + i];
         if (!STREAM) {
@@ -351,6 +345,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     }
     __syncthreads();
     unsigned step = 0;
+#if (LFGC_ABLATE & 8) && defined(LFGC_ANTIPHASE)
+    // diagnostics: with the barriers gone, start the second wave of every SIMD LFGC_ANTIPHASE x 8k cycles late
+    if (wave >= WAVES / 2) {
+#pragma unroll 1
+        for (int i = 0; i < LFGC_ANTIPHASE; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 #ifdef LFGC_STAMPS
     unsigned long long st_acc[16] = {0};
     unsigned long long st_last = __builtin_amdgcn_s_memtime();

@@ -271,9 +271,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a) {
             if (ki < p.H && ho < p.H) v = a.w[l][ho * p.H + ki];
         } else if (idx < p.off_hbias) {
             continue;                                         // scales: written by pack_scale_kernel
-        } else if (idx < p.off_hblk) {                        // b / pi of the hidden layers, [layer][row]
+        } else if (idx < p.off_hwf) {                         // b / pi of the hidden layers, [layer][row]
             const int l = (idx - p.off_hbias) / p.HP, r = (idx - p.off_hbias) % p.HP;
             if (l < p.L && r < p.H) v = (float)((double)a.b[l][r] / 3.14159265358979323846);
+        } else if (idx < p.off_hblk) {                        // head weights / LFGC_ACT_SCALE
+            const int r = idx - p.off_hwf;
+            if (r < p.H) v = (float)((double)a.w[p.L][r] / LFGC_ACT_SCALE);
         } else if (idx >= p.off_ht) {                         // f16-split transposed images: [row = k_in][k = h_out]
             const int o = idx - p.off_ht;
             const int l = o < p.tblk0 ? 0 : 1 + (o - p.tblk0) / p.tblk1;

@@ -55,7 +55,7 @@ def test_pure_host_entry_points(built_lib):
     HP, K0P, K0R, L = 128, 48, 64, 4
     fwd = HP * (K0P + 4) + HP + (L - 1) * (HP * (HP + 4) + HP) + HP + 4
     tr = K0R * (HP + 4) + (L - 1) * HP * (HP + 4)
-    h16 = 32 + 8 * HP + HP * (48 + 4) + HP + (L - 1) * (HP * (HP + 4) + HP)   # 2 x 16 scales + biases / pi + f16-split blocks (K0P16 = 48)
+    h16 = 32 + 8 * HP + HP + HP * (48 + 4) + HP + (L - 1) * (HP * (HP + 4) + HP)   # 2 x 16 scales + biases / pi + scaled head weights + f16-split blocks (K0P16 = 48)
     assert lib.lfgc_packed_bytes(ctypes.byref(ok)) == 4 * (fwd + tr + h16 + tr)     # + f16-split transposed images
     # stash: whole workgroup batches of 8 x 32 samples, 64 lanes x (KS0 + L*16*MT) floats per tile
     assert lib.lfgc_stash_bytes(ctypes.byref(ok), 1) == 4 * 8 * 64 * (24 + 4 * 64)
