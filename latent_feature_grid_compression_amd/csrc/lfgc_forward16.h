@@ -139,16 +139,24 @@ struct LfgcEpilogue {
     }
 };
 
+// A-operand queue: the fragments of the next LFGC_PF k-steps, read from LDS that many k-steps ahead of their MFMAs.
+#ifndef LFGC_PF
+#define LFGC_PF 2
+#endif
+struct LfgcOperands {
+    h16x8 hi[LFGC_PF], lo[LFGC_PF];
+};
+
 // The gaps of one output tile: G = KS16 * (SPLIT ? 3 : 1) MFMAs accumulating into `acc` (started from 0: the bias is
 // added in the epilogue), each followed by the A-operand read of the next k-step (or of `arow_next`'s first) and by its
 // slice of the pending epilogue `ep` of accumulator `eacc` (24 slots spread over the first GA gaps; GA = 0: nothing
 // pending).  The epilogue writes fragments Ehi / Elo; when these are IN's own last two (a tile carried over from the
 // previous layer, GA = gaps of the first KS16 - 2 k-steps) they are copied into IN before k-step KS16 - 2 reads them.
-// whi / wlo hold k-step 0's operands on entry and the next tile's on exit.
+// `w` holds the operands of this tile's first LFGC_PF k-steps on entry and of the next tile's on exit.
 template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, class EPI>
 __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, const float* __restrict__ arow_next,
                                                u32x4 (&INhi)[KS16], u32x4 (&INlo)[KS16], f32x16& acc,
-                                               h16x8& whi, h16x8& wlo, EPI& ep, const f32x16& eacc,
+                                               LfgcOperands& w, EPI& ep, const f32x16& eacc,
                                                u32x4 (&Ehi)[2], u32x4 (&Elo)[2], float& ydot, float& tmax) {
     constexpr int MPK = SPLIT ? 3 : 1;
     static_assert(!E_IS_IN_TAIL || GA <= (KS16 - 2) * MPK, "a carried tile must be done before the k-steps that read it");
@@ -160,7 +168,8 @@ __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, c
             INhi[KS16 - 2] = Ehi[0]; INhi[KS16 - 1] = Ehi[1];
             INlo[KS16 - 2] = Elo[0]; INlo[KS16 - 1] = Elo[1];
         }
-        h16x8 nhi = whi, nlo = wlo;
+        const h16x8 whi = w.hi[0], wlo = w.lo[0];          // this k-step's operands (read LFGC_PF k-steps ago)
+        h16x8 nhi = w.hi[LFGC_PF - 1], nlo = w.lo[LFGC_PF - 1];
         lfgc_static_for<MPK>([&](auto u_c) {
             constexpr int u = decltype(u_c)::value;
             constexpr int g = ks * MPK + u;
@@ -173,12 +182,16 @@ __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, c
             } else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh, acc, 0, 0, 0);
             }
-            const float* nsrc = (ks + 1 < KS16) ? arow + 16 * (ks + 1) : arow_next;      // one read per gap
+            // the operands of k-step ks + LFGC_PF (running on into the next tile's rows), one read per gap
+            const float* nsrc = (ks + LFGC_PF < KS16) ? arow + 16 * (ks + LFGC_PF)
+                                                      : (arow_next ? arow_next + 16 * (ks + LFGC_PF - KS16) : nullptr);
+#if !(LFGC_ABLATE & 32)             // diagnostics: 32 = no operand reads after the first k-steps'
             if (nsrc) {
                 if (u == 0) nhi = *reinterpret_cast<const h16x8*>(nsrc);
                 if (SPLIT && u == 1) nlo = *reinterpret_cast<const h16x8*>(nsrc + 4);
             }
-            if constexpr (GA > 0 && g < GA) {
+#endif
+            if constexpr (GA > 0 && g < GA && !(LFGC_ABLATE & 16)) {      // diagnostics: 16 = no epilogue under the MFMAs
                 constexpr int s_lo = g * 24 / GA, s_hi = (g + 1) * 24 / GA;
                 lfgc_static_for<s_hi - s_lo>([&](auto s_c) {
                     constexpr int s = s_lo + decltype(s_c)::value;
@@ -187,7 +200,9 @@ __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, c
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        whi = nhi; wlo = nlo;
+#pragma unroll
+        for (int d = 0; d + 1 < LFGC_PF; ++d) { w.hi[d] = w.hi[d + 1]; w.lo[d] = w.lo[d + 1]; }
+        w.hi[LFGC_PF - 1] = nhi; w.lo[LFGC_PF - 1] = nlo;
     });
 }
 
@@ -215,9 +230,13 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
     const float* wf_l = s_final + 4 * hh;
     float* stash_l = nullptr;
     if (STASH) { stash_l = stash + lane; asm volatile("" : "+v"(stash_l)); }
-    h16x8 whi = *reinterpret_cast<const h16x8*>(s_row);
-    h16x8 wlo = whi;
-    if (SPLIT) wlo = *reinterpret_cast<const h16x8*>(s_row + 4);
+    LfgcOperands w;
+#pragma unroll
+    for (int d = 0; d < LFGC_PF; ++d) {                        // (KS16 >= LFGC_PF for every compiled shape)
+        w.hi[d] = *reinterpret_cast<const h16x8*>(s_row + 16 * d);
+        w.lo[d] = w.hi[d];
+        if (SPLIT) w.lo[d] = *reinterpret_cast<const h16x8*>(s_row + 16 * d + 4);
+    }
 
     f32x16 accs[2];
     {   // tile 0: shadows the previous layer's last tile, which produces this layer's last two input fragments
@@ -235,7 +254,7 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
                 INhi[KS16 - 2] = ehi[0]; INhi[KS16 - 1] = ehi[1]; INlo[KS16 - 2] = elo[0]; INlo[KS16 - 1] = elo[1];
             }
         }
-        lfgc_tile_gaps<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0)>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo, accs[0], whi, wlo,
+        lfgc_tile_gaps<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0)>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo, accs[0], w,
                                                     ep, carry.acc, ehi, elo, ydot, tmax);
     }
     // tiles 1 .. MT-1: each shadows the tile before it
@@ -247,7 +266,7 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
         ep.begin();
         u32x4 ehi[2], elo[2];
         lfgc_tile_gaps<KS16, SPLIT, G, false>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr, INhi, INlo,
-                                              accs[m & 1], whi, wlo, ep, accs[(m - 1) & 1], ehi, elo, ydot, tmax);
+                                              accs[m & 1], w, ep, accs[(m - 1) & 1], ehi, elo, ydot, tmax);
         if (!LAST) {
             OUThi[2 * (m - 1)] = ehi[0]; OUThi[2 * (m - 1) + 1] = ehi[1];
             OUTlo[2 * (m - 1)] = elo[0]; OUTlo[2 * (m - 1) + 1] = elo[1];
