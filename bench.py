@@ -93,7 +93,7 @@ def cpu_baseline(model, w, budget_s=20.0, hip_volume=None):
     ``hip_volume`` (the volume the timed HIP path produced) the oracle's tiles also serve as the in-run parity check."""
     from oracle import ref_torch as R
     # the GPU box gives one-GPU jobs a 16-CPU share of its 256 hardware threads; torch oversubscribed to 256 threads
-    # runs this path 70x slower (tools/microbench/cpu_threads.py: 4..32 threads all give ~0.5 Msamples/s)
+    # runs this path 70x slower (tests/cpu_threads_microbench.py: 4..32 threads all give ~0.5 Msamples/s)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     coeffs = [p.detach().cpu() for p in model.feature_grid]
     layers = list(model.net_layers) + [model.final_layer]

@@ -1,7 +1,8 @@
 """Error of the fused forward per arithmetic build on the reference fixtures and on synthetic BASELINE shapes:
 max|y - y_ref| / max|y_ref| (the north_star bound, <= 1e-5) and the worst element of the allclose test
-(|y - y_ref| - rtol |y_ref|) / max|y_ref| (<= 2e-6 in tests/test_hip_forward.py).  GPU box only.
-    python tools/fwd_error_stats.py
+(|y - y_ref| - rtol |y_ref|) / max|y_ref| (<= 2e-6 in tests/test_hip_forward.py).  GPU box only.  Test infrastructure (it checks the HIP path against the oracle):
+lives under tests/, not collected by pytest.
+    python tests/error_stats.py
 """
 import glob
 import os
@@ -12,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))      # build_from_golden / build_synth of the parity tests
 from test_hip_forward import build_from_golden, build_synth, GOLD  # noqa: E402
 from oracle import ref_torch as R  # noqa: E402
 from oracle import ref_explicit as E  # noqa: E402

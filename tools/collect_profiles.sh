@@ -67,7 +67,7 @@ echo "== microbenchmarks"
 ./tools/microbench/mfma_shadow > $O/mfma_shadow.log 2>&1
 ./tools/microbench/hwcos_snake > $O/hwcos_snake.log 2>&1
 python3 tools/microbench/idwt_sizes.py > $O/idwt_sizes.log 2>&1; tail -4 $O/idwt_sizes.log
-python3 tools/fwd_error_stats.py > $O/fwd_error_stats.log 2>&1
+python3 tests/error_stats.py > $O/fwd_error_stats.log 2>&1
 [ -f tools/microbench/ablate/liblfgc_stamps.so ] && python3 tools/phase_stamps.py run > $O/phase_stamps.log 2>&1
 rm -rf $O/kt_*/ $O/pmc_*/
 ls $O
