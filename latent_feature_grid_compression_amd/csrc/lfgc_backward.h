@@ -33,7 +33,14 @@ struct LfgcBwdArgs {
     float* d_grid;             // (D,H,W,Cs), accumulated with float atomics
     float* d_pos;              // (N,3) or nullptr
     long long nbatches;
+    unsigned long long* stamps;   // diagnostics builds (-DLFGC_STAMPS, tools/phase_stamps.py bwd): per-wave cycle totals per phase
 };
+
+#ifdef LFGC_STAMPS
+#define LFGC_BSTAMP(k) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); bst[k] += now__ - bst_last; bst_last = now__; } while (0)
+#else
+#define LFGC_BSTAMP(k) do { } while (0)
+#endif
 
 // acc += W_tile . B for one 32-row M tile; `arow` = LDS address of (row 32m + lane&31, column 4*(lane>>5)).
 template <int KS>
@@ -50,22 +57,43 @@ __device__ __forceinline__ f32x16 lfgc_mfma_tile(const float* __restrict__ arow,
     return acc;
 }
 
-// dA[i] = dH[i] * snake'(a[i]) for the 16*MT pre-activations of one layer (a read from the stash slot).
+// dA[i] = dH[i] * snake'(a[i]) for the 16*MT pre-activations of one layer (read from the stash slot, which holds them in
+// turns of pi).  HW: the derivative from v_sin_f32 (f16 builds: 2 VALU per activation instead of ~25); the exact build,
+// and any tile with |t| beyond the hardware's domain, take Cody-Waite + polynomial on a = pi t.
 template <int MT>
-__device__ __forceinline__ void lfgc_snake_bwd(const float* __restrict__ slot, const float (&dH)[16 * MT],
-                                               float (&dA)[16 * MT], int lane) {
-    float av[16 * MT];
-    bool bad = false;
+__device__ __forceinline__ void lfgc_stash_load(const float* __restrict__ slot, float (&tv)[16 * MT], int lane) {
 #pragma unroll
-    for (int i = 0; i < 16 * MT; ++i) {
-        av[i] = slot[i * 64 + lane];
-        bad |= lfgc_trig_out_of_range(av[i]);
+    for (int i = 0; i < 16 * MT; ++i) tv[i] = slot[i * 64 + lane];
+}
+
+template <int MT, bool HW>
+__device__ __forceinline__ void lfgc_snake_bwd(float (&tv)[16 * MT], const float (&dH)[16 * MT],
+                                               float (&dA)[16 * MT]) {
+    bool poly = !HW;
+    if (HW) {
+        float tmax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16 * MT; i += 2) tmax = lfgc_absmax3(tmax, tv[i], tv[i + 1]);
+        poly = __any(!(tmax <= LFGC_TURNS_HW_MAX));               // wave-uniform; NaN / inf included
+        if (!poly) {
+#pragma unroll
+            for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_turns_hw(tv[i]);
+        }
     }
+    if (poly) {
+        bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<false>(av[i]);
-    if (__builtin_expect(__any(bad), 0)) {
+        for (int i = 0; i < 16 * MT; ++i) {
+            tv[i] *= 3.14159274101257324f;
+            bad |= lfgc_trig_out_of_range(tv[i]);
+        }
+        if (__builtin_expect(__any(bad), 0)) {
 #pragma unroll
-        for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<true>(av[i]);
+            for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<true>(tv[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<false>(tv[i]);
+        }
     }
 }
 
@@ -175,14 +203,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
     lfgc_dma_to_lds(image_src(L - 1), s_ring, (L - 1) == 0 ? TB0 : TB1, wave, lane, WAVES);
     __syncthreads();
     unsigned step = 0;
+#ifdef LFGC_STAMPS
+    unsigned long long bst[8] = {0};
+    unsigned long long bst_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long bst_t0 = bst_last;
+#endif
 
     const long long N = a.n;
     for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
         // the image of layer l was put in flight one step ago; after the barrier every wave is also done with the
         // other slot, so the next image (layer l-1, or the next batch's first) goes into it
         auto acquire = [&](int l) -> const float* {
+            LFGC_BSTAMP(1);                                   // snake' + dstash stores + scale + split
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            LFGC_BSTAMP(2);                                   // wait for stores / DMA + barrier
             const float* img = s_ring + (step & 1) * SLOT;
             const int ln = (l == 0) ? L - 1 : l - 1;
             if (l != 0 || batch + gridDim.x < a.nbatches)
@@ -207,10 +242,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             dH[4 * qb + 2] = w4.z * dy; dH[4 * qb + 3] = w4.w * dy;
         }
 
+        LFGC_BSTAMP(0);
+        // the stashed pre-activations of a layer are requested one layer ahead (after the barrier of the layer before, whose
+        // dA has consumed the registers), so that their HBM latency runs under that layer's MFMAs
+        float tv[16 * MT];
+        lfgc_stash_load<MT>(st_tile + 64 * KS0 + (long long)(L - 1) * (64 * 16 * MT), tv, lane);
         // ---- hidden layers L-1 .. 1 (0-based): dA = dH * snake'(a), dH_prev = W^T dA ------------------------
         for (int l = L - 1; l >= 1; --l) {
+            LFGC_BSTAMP(3);                                   // the MFMAs of the layer before (or the head's dH)
             float dA[16 * MT];
-            lfgc_snake_bwd<MT>(st_tile + 64 * KS0 + (long long)l * (64 * 16 * MT), dH, dA, lane);
+            lfgc_snake_bwd<MT, H16>(tv, dH, dA);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[(long long)l * (64 * 16 * MT) + i * 64 + lane] = dA[i];
             if (H16) {
@@ -220,6 +261,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 if (lane == 0) a.dscale[tile_idx * L + l] = sc;
                 lfgc_split_scaled<2 * MT, SPLIT>(dA, sc, Fhi, Flo);
                 const float* s_row = acquire(l) + j * ST + 8 * hh;
+                lfgc_stash_load<MT>(st_tile + 64 * KS0 + (long long)(l - 1) * (64 * 16 * MT), tv, lane);   // next layer's, under these MFMAs
                 const float is = s_inv[l] * isc;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -232,6 +274,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 }
             } else {
                 const float* s_row = acquire(l) + j * ST + 4 * hh;
+                lfgc_stash_load<MT>(st_tile + 64 * KS0 + (long long)(l - 1) * (64 * 16 * MT), tv, lane);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc;
@@ -248,7 +291,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         float dX[16 * TXA];
         {
             float dA[16 * MT];
-            lfgc_snake_bwd<MT>(st_tile + 64 * KS0, dH, dA, lane);
+            lfgc_snake_bwd<MT, H16>(tv, dH, dA);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[i * 64 + lane] = dA[i];
             h16x8 Fhi[2 * MT], Flo[2 * MT];
@@ -277,6 +320,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             }
         }
 
+        LFGC_BSTAMP(3);
         // ---- sampler geometry (same arithmetic as the forward) ---------------------------------------------
         const float* pp = a.pos + 3 * nc;
         const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
@@ -347,6 +391,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             }
         }
 
+        LFGC_BSTAMP(4);                                       // geometry + staging + atomic scatter
         // ---- d_pos = direct columns + Fourier embedding + sampler coordinate gradient ---------------------------
         if (a.d_pos) {
             float sk[NF > 0 ? NF : 1][3], ck[NF > 0 ? NF : 1][3];
@@ -396,7 +441,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 a.d_pos[3 * n + 0] = g0; a.d_pos[3 * n + 1] = g1; a.d_pos[3 * n + 2] = g2;
             }
         }
+        LFGC_BSTAMP(5);                                       // d_pos
     }
+#ifdef LFGC_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* dst = a.stamps + ((long long)blockIdx.x * WAVES + wave) * 20;
+        for (int k = 0; k < 8; ++k) dst[k] = bst[k];
+        dst[16] = __builtin_amdgcn_s_memtime() - bst_t0;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -420,6 +473,35 @@ __host__ __device__ inline int lfgc_slab_layer_off(const LfgcPlan& p, int l) {
     return l == 0 ? 0 : (p.HP * p.K0R + p.HP) + (l - 1) * (p.HP * p.HP + p.HP);
 }
 __host__ __device__ inline int lfgc_slab_floats(const LfgcPlan& p) { return lfgc_slab_layer_off(p, p.L) + p.HP + 4; }
+
+// H = SnakeAlt(a) of 16 stashed pre-activations (in turns of pi), in place.  hw: the f16 builds' form (v_cos_f32, as the
+// forward computed it); otherwise, and for tiles beyond the hardware's domain, Cody-Waite + polynomial on a = pi t.
+__device__ __forceinline__ void lfgc_snake_from_turns16(float (&v)[16], bool hw) {
+    if (hw) {
+        float tmax = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) tmax = lfgc_absmax3(tmax, v[s], v[s + 1]);
+        hw = !__any(!(tmax <= LFGC_TURNS_HW_MAX));
+    }
+    if (hw) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = lfgc_snake_turns_hw(v[s]);
+        return;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        v[s] *= 3.14159274101257324f;
+        bad |= lfgc_trig_out_of_range(v[s]);
+    }
+    if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = lfgc_snake_t<true>(v[s]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) v[s] = lfgc_snake_t<false>(v[s]);
+    }
+}
 
 // The 16 samples a lane contributes to a tile's contraction: [8 kh, 8 kh + 8) and [16 + 8 kh, 16 + 8 kh + 8) of stash row
 // `base` (= row start + lane-half offset): exactly the k values lane half kh feeds to the two 16-deep k-steps of
@@ -484,18 +566,7 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
                 for (int s = 0; s < 16; ++s) Bv[s] = 0.0f;
             }
         } else {
-            bool bad = false;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) bad |= lfgc_trig_out_of_range(Bv[s]);
-            float Hv[16];
-#pragma unroll
-            for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<false>(Bv[s]);
-            if (__builtin_expect(__any(bad), 0)) {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<true>(Bv[s]);
-            }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) Bv[s] = Hv[s];
+            lfgc_snake_from_turns16(Bv, a.dscale != nullptr);
         }
         bool split = a.dscale != nullptr;
         float sc = 1.0f, isc = 1.0f;
@@ -616,16 +687,8 @@ __global__ __launch_bounds__(512, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
             for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
                 float Bv[16];
                 lfgc_load16(a.stash + t * per_tile + boff, kk, Bv);
-                bool bad = false;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) bad |= lfgc_trig_out_of_range(Bv[s]);
-                float Hv[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<false>(Bv[s]);
-                if (__builtin_expect(__any(bad), 0)) {
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<true>(Bv[s]);
-                }
+                lfgc_snake_from_turns16(Bv, a.dscale != nullptr);
+                const float (&Hv)[16] = Bv;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const long long smp = t * 32 + 8 * kk + 16 * (s >> 3) + (s & 7);       // lfgc_load16's sample order

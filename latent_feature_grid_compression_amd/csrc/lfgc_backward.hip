@@ -6,6 +6,12 @@ int lfgc_bwd_dispatch_ch16(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, i
 int lfgc_bwd_dispatch_ch24(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
 int lfgc_bwd_dispatch_ch32(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
 
+#ifdef LFGC_STAMPS
+static unsigned long long* g_bwd_stamps = nullptr;
+// Diagnostics builds only (tools/phase_stamps.py bwd): device buffer of 20 counters per wave slot of the data kernel.
+extern "C" void lfgc_debug_set_bwd_stamp_buffer(void* p) { g_bwd_stamps = reinterpret_cast<unsigned long long*>(p); }
+#endif
+
 namespace {
 #ifndef LFGC_MAX_SLABS
 #define LFGC_MAX_SLABS 256
@@ -79,6 +85,10 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     a.grid = grid_cl; a.D = D; a.H = H; a.W = W; a.Cs = p.CH;
     a.packed = packed; a.L = p.L; a.stash = stash; a.d_out = d_out;
     a.dstash = dstash; a.dscale = dscale; a.d_grid = d_grid_cl; a.d_pos = d_pos;
+    a.stamps = nullptr;
+#ifdef LFGC_STAMPS
+    a.stamps = g_bwd_stamps;
+#endif
 
     LfgcWgradArgs w;
     w.stash = stash; w.dstash = dstash; w.d_out = d_out; w.n = n; w.ntiles = c.ntiles; w.L = p.L;

@@ -24,9 +24,31 @@ else:
     import bench
     from latent_feature_grid_compression_amd import _lib, ops
     dev = torch.device('cuda:0')
-    w = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else 'headline']
+    w = bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != 'bwd' else 'headline']
     model = bench.build_model(w, 1234, dev)
     lib = _lib.load()
+    if len(sys.argv) > 2 and sys.argv[2] == 'bwd':
+        # backward data kernel at the cfg-3 train-step batch
+        n = 32768
+        nslots = 256 * 8
+        buf = torch.zeros(nslots * 20, dtype=torch.int64, device=dev)
+        lib.lfgc_debug_set_bwd_stamp_buffer.argtypes = [ctypes.c_void_p]
+        lib.lfgc_debug_set_bwd_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+        model = bench.build_model(bench.WORKLOADS['headline'], 1234, dev).train()
+        for _ in range(3):
+            pos = (torch.rand(n, 3, device=dev) * 2 - 1).requires_grad_(True)
+            model.zero_grad()
+            model(pos).square().mean().backward()
+        torch.cuda.synchronize()
+        s = buf.cpu().numpy().reshape(nslots, 20).astype(np.float64)
+        s = s[s[:, 16] > 0]
+        names = {0: "head dH + loop", 1: "snake' (stash loads), dstash stores, scale, split", 2: 'wait for stores / weight DMA + barrier',
+                 3: 'MFMAs + scale-back', 4: 'geometry, staging, atomic scatter', 5: 'd_pos'}
+        tot = s[:, 16].mean()
+        print('bwd data kernel: waves %d, wave lifetime %.0f cycles' % (len(s), tot))
+        for k in sorted(names):
+            print('  %-52s %9.0f cycles  %5.1f %%' % (names[k], s[:, k].mean(), 100 * s[:, k].mean() / tot))
+        sys.exit(0)
     nslots = 256 * 8
     buf = torch.zeros(nslots * 20, dtype=torch.int64, device=dev)
     lib.lfgc_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
