@@ -31,6 +31,8 @@ struct LfgcBwdArgs {
     float* dstash;             // [tiles][L*16*MT][64]
     float* dscale;             // [tiles][L]: the power-of-two scale each tile's dA_l was split with (f16 builds), for the weight kernel
     float* d_grid;             // (D,H,W,Cs), accumulated with float atomics
+    float* dfeat;              // nullptr: the data kernel scatters into d_grid itself; else (tiles*32, CH) scratch: it only
+                               // writes the feature gradients there and lfgc_bwd_scatter_kernel does the atomics
     float* d_pos;              // (N,3) or nullptr
     long long nbatches;
     unsigned long long* stamps;   // diagnostics builds (-DLFGC_STAMPS, tools/phase_stamps.py bwd): per-wave cycle totals per phase
@@ -57,43 +59,22 @@ __device__ __forceinline__ f32x16 lfgc_mfma_tile(const float* __restrict__ arow,
     return acc;
 }
 
-// dA[i] = dH[i] * snake'(a[i]) for the 16*MT pre-activations of one layer (read from the stash slot, which holds them in
-// turns of pi).  HW: the derivative from v_sin_f32 (f16 builds: 2 VALU per activation instead of ~25); the exact build,
-// and any tile with |t| beyond the hardware's domain, take Cody-Waite + polynomial on a = pi t.
+// dA[i] = dH[i] * snake'(a[i]) for the 16*MT pre-activations of one layer (a read from the stash slot).
 template <int MT>
-__device__ __forceinline__ void lfgc_stash_load(const float* __restrict__ slot, float (&tv)[16 * MT], int lane) {
+__device__ __forceinline__ void lfgc_snake_bwd(const float* __restrict__ slot, const float (&dH)[16 * MT],
+                                               float (&dA)[16 * MT], int lane) {
+    float av[16 * MT];
+    bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 16 * MT; ++i) tv[i] = slot[i * 64 + lane];
-}
-
-template <int MT, bool HW>
-__device__ __forceinline__ void lfgc_snake_bwd(float (&tv)[16 * MT], const float (&dH)[16 * MT],
-                                               float (&dA)[16 * MT]) {
-    bool poly = !HW;
-    if (HW) {
-        float tmax = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16 * MT; i += 2) tmax = lfgc_absmax3(tmax, tv[i], tv[i + 1]);
-        poly = __any(!(tmax <= LFGC_TURNS_HW_MAX));               // wave-uniform; NaN / inf included
-        if (!poly) {
-#pragma unroll
-            for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_turns_hw(tv[i]);
-        }
+    for (int i = 0; i < 16 * MT; ++i) {
+        av[i] = slot[i * 64 + lane];
+        bad |= lfgc_trig_out_of_range(av[i]);
     }
-    if (poly) {
-        bool bad = false;
 #pragma unroll
-        for (int i = 0; i < 16 * MT; ++i) {
-            tv[i] *= 3.14159274101257324f;
-            bad |= lfgc_trig_out_of_range(tv[i]);
-        }
-        if (__builtin_expect(__any(bad), 0)) {
+    for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<false>(av[i]);
+    if (__builtin_expect(__any(bad), 0)) {
 #pragma unroll
-            for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<true>(tv[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<false>(tv[i]);
-        }
+        for (int i = 0; i < 16 * MT; ++i) dA[i] = dH[i] * lfgc_snake_grad_t<true>(av[i]);
     }
 }
 
@@ -214,7 +195,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         // the image of layer l was put in flight one step ago; after the barrier every wave is also done with the
         // other slot, so the next image (layer l-1, or the next batch's first) goes into it
         auto acquire = [&](int l) -> const float* {
-            LFGC_BSTAMP(1);                                   // snake' + dstash stores + scale + split
+            LFGC_BSTAMP(1);                                   // snake' (stash loads) + dstash stores + scale + split
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             LFGC_BSTAMP(2);                                   // wait for stores / DMA + barrier
@@ -243,15 +224,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         }
 
         LFGC_BSTAMP(0);
-        // the stashed pre-activations of a layer are requested one layer ahead (after the barrier of the layer before, whose
-        // dA has consumed the registers), so that their HBM latency runs under that layer's MFMAs
-        float tv[16 * MT];
-        lfgc_stash_load<MT>(st_tile + 64 * KS0 + (long long)(L - 1) * (64 * 16 * MT), tv, lane);
         // ---- hidden layers L-1 .. 1 (0-based): dA = dH * snake'(a), dH_prev = W^T dA ------------------------
         for (int l = L - 1; l >= 1; --l) {
             LFGC_BSTAMP(3);                                   // the MFMAs of the layer before (or the head's dH)
             float dA[16 * MT];
-            lfgc_snake_bwd<MT, H16>(tv, dH, dA);
+            lfgc_snake_bwd<MT>(st_tile + 64 * KS0 + (long long)l * (64 * 16 * MT), dH, dA, lane);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[(long long)l * (64 * 16 * MT) + i * 64 + lane] = dA[i];
             if (H16) {
@@ -261,7 +238,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 if (lane == 0) a.dscale[tile_idx * L + l] = sc;
                 lfgc_split_scaled<2 * MT, SPLIT>(dA, sc, Fhi, Flo);
                 const float* s_row = acquire(l) + j * ST + 8 * hh;
-                lfgc_stash_load<MT>(st_tile + 64 * KS0 + (long long)(l - 1) * (64 * 16 * MT), tv, lane);   // next layer's, under these MFMAs
                 const float is = s_inv[l] * isc;
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
@@ -274,7 +250,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 }
             } else {
                 const float* s_row = acquire(l) + j * ST + 4 * hh;
-                lfgc_stash_load<MT>(st_tile + 64 * KS0 + (long long)(l - 1) * (64 * 16 * MT), tv, lane);
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     f32x16 acc;
@@ -291,7 +266,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         float dX[16 * TXA];
         {
             float dA[16 * MT];
-            lfgc_snake_bwd<MT, H16>(tv, dH, dA);
+            lfgc_snake_bwd<MT>(st_tile + 64 * KS0, dH, dA, lane);
 #pragma unroll
             for (int i = 0; i < 16 * MT; ++i) dst_tile[i * 64 + lane] = dA[i];
             h16x8 Fhi[2 * MT], Flo[2 * MT];
@@ -337,8 +312,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         const bool in_range = (fx0 >= -1.0f) && (fx0 < (float)a.W) && (fy0 >= -1.0f) && (fy0 < (float)a.H) &&
                               (fz0 >= -1.0f) && (fz0 < (float)a.D);
 
-        // ---- scatter d feat into d_grid: stage [sample][channel] + per-corner weight/offset in LDS ----------
-        __syncthreads();                                  // every wave is done with the layer-0 image: reuse its slot
+        // ---- scatter d feat into d_grid ----------------------------------------------------------------------
+        // in-kernel (throughput mode: other waves' work covers the atomics' latency): stage [sample][channel] +
+        // per-corner weight / offset in LDS, then one atomic wave-instruction per 64 / CH samples and corner;
+        // deferred (a.dfeat; small batches, one wave per SIMD: 128 dependent-latency atomics per wave were 40 % of
+        // this kernel): only write the feature gradients out, lfgc_bwd_scatter_kernel scatters them at full occupancy
+        const bool stage = a.dfeat == nullptr;            // uniform
+        if (stage) __syncthreads();                       // every wave is done with the layer-0 image: reuse its slot
         float* s_df = s_ring + ((step - 1) & 1) * SLOT + wave * SC_WAVE;   // [32][SCS]
         float* s_cw = s_df + 32 * SCS;                    // [32][8] corner weights
         int* s_co = reinterpret_cast<int*>(s_cw + 32 * 8);   // [32][8] corner row offsets (floats)
@@ -346,9 +326,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         for (int c4 = 0; c4 < CHH / 4; ++c4) {
             f32x4 v;
             v.x = dX[4 * c4 + 0]; v.y = dX[4 * c4 + 1]; v.z = dX[4 * c4 + 2]; v.w = dX[4 * c4 + 3];
-            *reinterpret_cast<f32x4*>(s_df + j * SCS + hh * CHH + 4 * c4) = v;
+            if (stage) *reinterpret_cast<f32x4*>(s_df + j * SCS + hh * CHH + 4 * c4) = v;
+            else *reinterpret_cast<f32x4*>(a.dfeat + (tile_idx * 32 + j) * CH + hh * CHH + 4 * c4) = v;
         }
         float gix = 0.0f, giy = 0.0f, giz = 0.0f;
+        if (stage || a.d_pos) {
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
             const int dz = corner >> 2, dyc = (corner >> 1) & 1, dx = corner & 1;
@@ -358,7 +340,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             const float w = ok ? __fmul_rn(__fmul_rn(wxc, wyc), wzc) : 0.0f;
             const int xc = min(max(xi, 0), a.W - 1), yc = min(max(yi, 0), a.H - 1), zc = min(max(zi, 0), a.D - 1);
             const long long off = ((long long)(zc * a.H + yc) * a.W + xc) * a.Cs;
-            if (hh == 0) s_cw[j * 8 + corner] = w; else s_co[j * 8 + corner] = (int)off;
+            if (stage) { if (hh == 0) s_cw[j * 8 + corner] = w; else s_co[j * 8 + corner] = (int)off; }
             if (a.d_pos && ok) {                           // sampler coordinate gradient (ATen grid_sampler_3d_backward)
                 const float* gp = a.grid + off + hh * CHH;
                 float dot = 0.0f;
@@ -373,8 +355,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                 giz += (dz ? dot : -dot) * (wxc * wyc);
             }
         }
-        __syncthreads();                                  // staging visible to every lane that reads it
-        {
+        }
+        if (stage) {
+            __syncthreads();                              // staging visible to every lane that reads it
             const int sp = lane / CH, c = lane % CH;
             if (sp < SPI) {
                 for (int i = 0; i < (32 + SPI - 1) / SPI; ++i) {
@@ -452,6 +435,46 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
 #endif
 }
 
+// Deferred scatter of the feature gradients (small batches): d_grid[corner rows of sample n] += w_corner * dfeat[n].
+// A wave takes 8 samples, 64 / CH at a time (one atomic wave-instruction = that many whole channel rows), every lane
+// forming its sample's corner weights and offsets itself with the forward's arithmetic; thousands of waves, so the
+// float atomics' latency (a cold line per row) is covered by occupancy instead of being waited for 128 times in a row.
+template <int CH>
+__global__ __launch_bounds__(256) void lfgc_bwd_scatter_kernel(const float* __restrict__ pos, const float* __restrict__ dfeat,
+                                                              float* __restrict__ d_grid, long long n, int D, int H, int W, int Cs) {
+    constexpr int SPI = 64 / CH;                          // samples per wave-instruction
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int sp = lane / CH, c = lane % CH;
+    if (sp >= SPI) return;
+#pragma unroll 1
+    for (int i = 0; i < 8 / SPI + (8 % SPI != 0); ++i) {
+        const long long smp = gw * 8 + i * SPI + sp;
+        if (i * SPI + sp >= 8 || smp >= n) continue;
+        const float p0 = pos[3 * smp], p1 = pos[3 * smp + 1], p2 = pos[3 * smp + 2];
+        const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p0, 1.0f), (float)W), 1.0f), 0.5f);
+        const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p1, 1.0f), (float)H), 1.0f), 0.5f);
+        const float iz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p2, 1.0f), (float)D), 1.0f), 0.5f);
+        const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+        const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)W);
+        const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)H);
+        const int z0 = (int)fminf(fmaxf(fz0, -2.0f), (float)D);
+        float wx[2], wy[2], wz[2];
+        wx[1] = __fsub_rn(ix, fx0); wx[0] = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+        wy[1] = __fsub_rn(iy, fy0); wy[0] = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+        wz[1] = __fsub_rn(iz, fz0); wz[0] = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
+        const float v = dfeat[smp * CH + c];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int dz = corner >> 2, dy = (corner >> 1) & 1, dx = corner & 1;
+            const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+            const bool ok = (unsigned)xi < (unsigned)W && (unsigned)yi < (unsigned)H && (unsigned)zi < (unsigned)D;
+            const float w = __fmul_rn(__fmul_rn(wx[dx], wy[dy]), wz[dz]);
+            if (ok && w != 0.0f) atomicAdd(d_grid + ((long long)(zi * H + yi) * W + xi) * Cs + c, v * w);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // weight gradients
 // ---------------------------------------------------------------------------------------------------------
@@ -473,35 +496,6 @@ __host__ __device__ inline int lfgc_slab_layer_off(const LfgcPlan& p, int l) {
     return l == 0 ? 0 : (p.HP * p.K0R + p.HP) + (l - 1) * (p.HP * p.HP + p.HP);
 }
 __host__ __device__ inline int lfgc_slab_floats(const LfgcPlan& p) { return lfgc_slab_layer_off(p, p.L) + p.HP + 4; }
-
-// H = SnakeAlt(a) of 16 stashed pre-activations (in turns of pi), in place.  hw: the f16 builds' form (v_cos_f32, as the
-// forward computed it); otherwise, and for tiles beyond the hardware's domain, Cody-Waite + polynomial on a = pi t.
-__device__ __forceinline__ void lfgc_snake_from_turns16(float (&v)[16], bool hw) {
-    if (hw) {
-        float tmax = 0.0f;
-#pragma unroll
-        for (int s = 0; s < 16; s += 2) tmax = lfgc_absmax3(tmax, v[s], v[s + 1]);
-        hw = !__any(!(tmax <= LFGC_TURNS_HW_MAX));
-    }
-    if (hw) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) v[s] = lfgc_snake_turns_hw(v[s]);
-        return;
-    }
-    bool bad = false;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        v[s] *= 3.14159274101257324f;
-        bad |= lfgc_trig_out_of_range(v[s]);
-    }
-    if (__builtin_expect(__any(bad), 0)) {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) v[s] = lfgc_snake_t<true>(v[s]);
-    } else {
-#pragma unroll
-        for (int s = 0; s < 16; ++s) v[s] = lfgc_snake_t<false>(v[s]);
-    }
-}
 
 // The 16 samples a lane contributes to a tile's contraction: [8 kh, 8 kh + 8) and [16 + 8 kh, 16 + 8 kh + 8) of stash row
 // `base` (= row start + lane-half offset): exactly the k values lane half kh feeds to the two 16-deep k-steps of
@@ -566,7 +560,18 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
                 for (int s = 0; s < 16; ++s) Bv[s] = 0.0f;
             }
         } else {
-            lfgc_snake_from_turns16(Bv, a.dscale != nullptr);
+            bool bad = false;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) bad |= lfgc_trig_out_of_range(Bv[s]);
+            float Hv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<false>(Bv[s]);
+            if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<true>(Bv[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) Bv[s] = Hv[s];
         }
         bool split = a.dscale != nullptr;
         float sc = 1.0f, isc = 1.0f;
@@ -687,8 +692,16 @@ __global__ __launch_bounds__(512, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
             for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
                 float Bv[16];
                 lfgc_load16(a.stash + t * per_tile + boff, kk, Bv);
-                lfgc_snake_from_turns16(Bv, a.dscale != nullptr);
-                const float (&Hv)[16] = Bv;
+                bool bad = false;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) bad |= lfgc_trig_out_of_range(Bv[s]);
+                float Hv[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<false>(Bv[s]);
+                if (__builtin_expect(__any(bad), 0)) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) Hv[s] = lfgc_snake_t<true>(Bv[s]);
+                }
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const long long smp = t * 32 + 8 * kk + 16 * (s >> 3) + (s & 7);       // lfgc_load16's sample order
@@ -801,6 +814,12 @@ static int lfgc_launch_bwd(const LfgcBwdArgs& a, const LfgcWgradArgs& w, int wav
     else rc = waves == 8 ? lfgc_launch_bwd_data<CH, MT, NF, 8, 0>(a, lds_bytes, grid_data, stream)
                          : lfgc_launch_bwd_data<CH, MT, NF, 4, 0>(a, lds_bytes, grid_data, stream);
     if (rc != LFGC_OK) return rc;
+    if (a.dfeat) {                                        // deferred scatter of the feature gradients
+        const long long blocks = (a.n + 31) / 32;         // 4 waves x 8 samples
+        hipLaunchKernelGGL(lfgc_bwd_scatter_kernel<CH>, dim3((unsigned)blocks), dim3(256), 0, stream, a.pos, a.dfeat, a.d_grid, a.n,
+                           a.D, a.H, a.W, a.Cs);
+        LFGC_HIP_CHECK_LAUNCH();
+    }
     {
         constexpr int K0R_ = (CH + (3 + 6 * NF + 7) / 8 * 8 + 31) / 32 * 32;
         constexpr int NT0_ = K0R_ / 32;

@@ -1,4 +1,5 @@
 // lfgc_backward.hip -- C-ABI entry for the backward of the fused path: checks, workspace carving, dispatch.
+#include <cstdlib>
 #include "lfgc_backward.h"
 
 int lfgc_bwd_dispatch_ch8(int, const LfgcBwdArgs&, const LfgcWgradArgs&, int, int, int, int, int, hipStream_t);
@@ -21,7 +22,7 @@ const int kMaxSlabs = LFGC_MAX_SLABS;   // workgroups of the weight-gradient ker
 struct Carve {
     long long ntiles, nbatches;
     int nslabs;
-    long long dstash_floats, slab_floats_total, dscale_floats;
+    long long dstash_floats, slab_floats_total, dscale_floats, dfeat_floats;
 };
 
 Carve carve(const LfgcPlan& p, long long n) {
@@ -33,6 +34,7 @@ Carve carve(const LfgcPlan& p, long long n) {
     c.dstash_floats = c.ntiles * 64LL * (p.L * 16 * p.MT);
     c.slab_floats_total = (long long)c.nslabs * lfgc_slab_floats(p);
     c.dscale_floats = (c.ntiles * p.L + 3) / 4 * 4;     // one power-of-two scale per (tile, layer), f16 builds
+    c.dfeat_floats = c.ntiles * 32 * p.CH;              // feature gradients for the deferred scatter (small batches)
     return c;
 }
 }  // namespace
@@ -42,7 +44,7 @@ extern "C" int64_t lfgc_backward_workspace_bytes(const lfgc_mlp_desc* desc, int6
     if (n_samples < 0) return LFGC_E_SHAPE;
     const LfgcPlan p = lfgc_make_plan(desc->grid_channels, desc->hidden, desc->num_layers, desc->n_freqs);
     const Carve c = carve(p, n_samples);
-    return (c.dstash_floats + c.slab_floats_total + c.dscale_floats) * 4;
+    return (c.dstash_floats + c.slab_floats_total + c.dscale_floats + c.dfeat_floats) * 4;
 }
 
 extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
@@ -75,10 +77,11 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
         return LFGC_OK;
     }
     const Carve c = carve(p, n);
-    if (!workspace || workspace_bytes < (c.dstash_floats + c.slab_floats_total + c.dscale_floats) * 4) return LFGC_E_WORKSPACE;
+    if (!workspace || workspace_bytes < (c.dstash_floats + c.slab_floats_total + c.dscale_floats + c.dfeat_floats) * 4) return LFGC_E_WORKSPACE;
     float* dstash = reinterpret_cast<float*>(workspace);
     float* slabs = dstash + c.dstash_floats;
     float* dscale = slabs + c.slab_floats_total;
+    float* dfeat = dscale + c.dscale_floats;
 
     LfgcBwdArgs a;
     a.pos = positions->pos; a.n = n;
@@ -99,6 +102,14 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     // data kernel: one workgroup per CU, 8 waves once every CU gets a 256-sample batch, else 4 (tiles beyond the
     // last whole 128-sample group are never touched: the stash covers whole 256-sample groups, lfgc_stash_bytes)
     const int waves = ((n + 255) / 256 >= cus) ? 8 : 4;
+    // Feature-gradient scatter: inside the data kernel.  LFGC_SCATTER=deferred (diagnostics) moves the float atomics into
+    // a kernel of their own at full occupancy: measured at the cfg-3 train step, the data kernel drops from 78 to 54 us and
+    // the scatter kernel takes 29 us -- 8.4 M device-scope float adds on cold lines cost that much either way (the
+    // in-kernel phase stamps' 40 % "scatter" share is their latency, not an occupancy problem), so the step does not move.
+    {
+        const char* env = getenv("LFGC_SCATTER");
+        a.dfeat = (env && env[0] == 'd') ? dfeat : nullptr;
+    }
     a.nbatches = c.nbatches * (8 / waves);              // same tile range as the forward wrote
     const int tb0 = p.K0R * p.ST, tb1 = p.HP * p.ST, sc = waves * 32 * (p.CH + 4 + 16);
     int slot = tb0 > tb1 ? tb0 : tb1;

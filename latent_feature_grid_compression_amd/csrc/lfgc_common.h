@@ -253,17 +253,6 @@ __device__ __forceinline__ void lfgc_dma_to_lds(const float* __restrict__ gsrc, 
     }
 }
 
-// SnakeAlt and its derivative from a pre-activation in turns of pi (the stash's form), on the hardware sine / cosine
-// (revolutions in, exact argument reduction, abs error 1.25e-7; tools/microbench/hwcos_snake.hip):
-//   snake(a)  = (pi/2) t + (1 - cos 2 pi t) / 2        snake'(a) = 1/2 + sin 2a = 1/2 + sin 2 pi t
-// Valid for |t| <= 256 (v_sin/v_cos's domain); callers screen the tile and fall back to the polynomial forms on a = pi t.
-#define LFGC_TURNS_HW_MAX 255.0f
-__device__ __forceinline__ float lfgc_snake_turns_hw(float t) {
-    const float e = __builtin_fmaf(t, -4.371138828673793e-08f, __builtin_fmaf(__builtin_amdgcn_cosf(t), -0.5f, 0.5f));
-    return __builtin_fmaf(t, 1.5707963705062866f, e);           // pi/2 as a two-term constant, linear part last
-}
-__device__ __forceinline__ float lfgc_snake_grad_turns_hw(float t) { return 0.5f + __builtin_amdgcn_sinf(t); }
-
 // d SnakeAlt / da = 0.5 + 2 sin a cos a
 template <bool WIDE>
 __device__ __forceinline__ float lfgc_snake_grad_t(float a) {

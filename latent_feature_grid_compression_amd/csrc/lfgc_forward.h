@@ -284,12 +284,10 @@ __device__ __forceinline__ void lfgc_layer_fwd(const float* __restrict__ s_blk, 
         if (STASH) {
             // one opaque row pointer per tile + immediate offsets (r * 256 B): otherwise hipcc hoists a 64-bit
             // address per store out of the batch loop and spills ~60 VGPRs
-            // the stash holds pre-activations in TURNS OF PI (t = a / pi), the form the f16 build computes in: the
-            // backward kernels take sin(2a), cos(2a) of it from v_sin_f32 / v_cos_f32, which want revolutions
             float* pm = stash + m * (16 * 64) + lane;
             asm volatile("" : "+v"(pm));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pm[r * 64] = acc[r] * 0.31830987334251404f;
+            for (int r = 0; r < 16; ++r) pm[r * 64] = acc[r];
         }
         float amax = 0.0f;
 #pragma unroll

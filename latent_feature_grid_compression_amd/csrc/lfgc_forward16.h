@@ -117,9 +117,9 @@ struct LfgcEpilogue {
             t0 = __builtin_fmaf(acc[2 * P], inv_scale, bq[Q & 1][I]);
             t1 = __builtin_fmaf(acc[2 * P + 1], inv_scale, bq[Q & 1][I + 1]);
             c0 = __builtin_amdgcn_cosf(t0);                              // cos(2 pi t)
-            if (STASH) {                                                  // the backward kernels read t = a / pi
-                stash[(2 * P) * 64] = t0;
-                stash[(2 * P + 1) * 64] = t1;
+            if (STASH) {                                                  // the backward kernels read a = pi t
+                stash[(2 * P) * 64] = t0 * 3.14159274101257324f;
+                stash[(2 * P + 1) * 64] = t1 * 3.14159274101257324f;
             }
             if (LAST) tmax = lfgc_absmax3(tmax, t0, t1);
         } else if constexpr (S == 1) {

@@ -227,7 +227,7 @@ def _decode_stash(stash, n, KS0, L, MT):
 
 @pytest.mark.parametrize('precision', PRECISIONS)
 def test_stash_holds_reference_preactivations(dev, precision):
-    """The values saved for backward are the reference's layer-0 input and pre-activations (the latter divided by pi)."""
+    """The values saved for backward are the reference's layer-0 input and pre-activations."""
     from latent_feature_grid_compression_amd import ops
     g = np.load(os.path.join(GOLD, 'fwd_cfg1_c16g16h32l2.npz'))
     m = build_from_golden(g, dev)
@@ -250,8 +250,8 @@ def test_stash_holds_reference_preactivations(dev, precision):
             assert np.all(x0[:, cl] == 0)
         else:
             assert np.abs(x0[:, cl] - ref_x0[:, src]).max() < 2e-6, (cl, src)
-    for l in range(L):          # pre-activations are saved in turns of pi (t = a / pi: what v_sin/v_cos_f32 take)
-        assert np.abs(pre[l][:, :H] * np.float32(np.pi) - g['pre%d' % l]).max() < 1e-5 * max(1.0, np.abs(g['pre%d' % l]).max())
+    for l in range(L):
+        assert np.abs(pre[l][:, :H] - g['pre%d' % l]).max() < 1e-5 * max(1.0, np.abs(g['pre%d' % l]).max())
 
 
 @pytest.mark.parametrize('C,G,H,L,n,tol', [
