@@ -76,6 +76,19 @@ int lfgc_idwt_level_bwd_f32(const float* d_out, const float* filter_rev, const f
 int lfgc_grid_layout_f32(const float* src, float* dst, int C, int64_t voxels, int channel_stride,
                          int to_channel_last, lfgc_stream_t stream);
 
+/* The LAST level of decode_volume() written straight in the sampler's channel-last layout, and its adjoint reading the
+ * gradient of that layout: lfgc_idwt_level_f32 + lfgc_grid_layout_f32 (and lfgc_grid_layout_f32 +
+ * lfgc_idwt_level_bwd_f32) in one pass over the data each (wavelet_transform/Torch_Wavelet_Transform.py:91-104, crop
+ * :69-73; the permute is this library's, the reference samples the channel-first grid).
+ *   out_cl / d_out_cl  device (t0,t1,t2, channel_stride), channel_stride = lfgc_grid_channel_stride(C); pad channels
+ *                      are written as 0 / ignored
+ *   taps               REQUIRED (separable bank, see above).  Returns LFGC_E_UNSUPPORTED for taps == NULL, C > 32 or
+ *                      arrays of 2^30 bytes and more: the caller then composes the two channel-first entry points. */
+int lfgc_idwt_level_cl_f32(const float* lll, const float* hf, const float* taps, float* out_cl,
+                           int C, int channel_stride, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
+int lfgc_idwt_level_cl_bwd_f32(const float* d_out_cl, const float* taps, float* d_lll, float* d_hf,
+                               int C, int channel_stride, int d0, int d1, int d2, int t0, int t1, int t2, lfgc_stream_t stream);
+
 /* One forward-DWT level (init only).  Replaces _WaveletFilterNd.encode incl. _pad_for_forward
  * (wavelet_transform/Torch_Wavelet_Transform.py:59-67, :75-89): zero-pad (2, 2 + odd) per axis,
  * grouped conv3d stride 2.  in (C, n0,n1,n2) -> out (C, 8, d0,d1,d2), d_a = (n_a + pad_hi_a) / 2 + 1 - ...

@@ -42,6 +42,8 @@ SIGNATURES = {
     'lfgc_error_string': (c_char_p, [c_int]),
     'lfgc_idwt_level_f32': (c_int, [c_void_p, c_void_p, c_void_p, _TAPS, c_void_p] + [c_int] * 7 + [c_void_p]),
     'lfgc_idwt_level_bwd_f32': (c_int, [c_void_p, c_void_p, _TAPS, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'lfgc_idwt_level_cl_f32': (c_int, [c_void_p, c_void_p, _TAPS, c_void_p] + [c_int] * 8 + [c_void_p]),
+    'lfgc_idwt_level_cl_bwd_f32': (c_int, [c_void_p, _TAPS, c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     'lfgc_grid_layout_f32': (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     'lfgc_dwt_level_f32': (c_int, [c_void_p, c_void_p, _TAPS, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'lfgc_idwt_level_drop_f32': (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_float, c_void_p, _TAPS, c_void_p] +

@@ -209,12 +209,66 @@ def dwt_level(data: torch.Tensor, filter_fwd: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_E_UNSUPPORTED = -3
+
+
+def _cl_level_ok(C: int, d: Sequence[int], t: Sequence[int], taps) -> bool:
+    """Shapes the channel-last last-level kernels take (lfgc.h: lfgc_idwt_level_cl_f32): separable bank, C <= 32,
+    arrays below 2^30 bytes.  Anything else composes the channel-first level with the layout conversion."""
+    if taps is None or C > 32 or os.environ.get('LFGC_CL_LEVEL', '1') == '0':
+        return False
+    cs = grid_channel_stride(C)
+    return t[0] * t[1] * t[2] * cs * 4 < (1 << 30) and d[0] * d[1] * d[2] * 7 * C * 4 < (1 << 30)
+
+
+@_on_device
+def idwt_level_cl(lll: torch.Tensor, hf: torch.Tensor, filter_rev: torch.Tensor, target: Sequence[int]) -> torch.Tensor:
+    """lll (C,d0,d1,d2), hf (C,7,d0,d1,d2) -> (t0,t1,t2,Cs) channel-last, pad channels zero: the last level of the
+    decode and the layout conversion in one kernel (falls back to the two-kernel form for shapes it does not take)."""
+    _require_hip(lll, hf, filter_rev)
+    taps = filter_taps(filter_rev)
+    C, d0, d1, d2 = lll.shape
+    t = [int(v) for v in target]
+    if not _cl_level_ok(C, (d0, d1, d2), t, taps):
+        return to_channel_last(idwt_level(lll, hf, filter_rev, target))
+    lll, hf = _f32c(lll), _f32c(hf)
+    if tuple(hf.shape) != (C, 7, d0, d1, d2):
+        raise ValueError('detail bands %s do not match low band %s' % (tuple(hf.shape), tuple(lll.shape)))
+    cs = grid_channel_stride(C)
+    out = torch.empty((t[0], t[1], t[2], cs), dtype=torch.float32, device=lll.device)
+    check(_lib.load().lfgc_idwt_level_cl_f32(lll.data_ptr(), hf.data_ptr(), taps, out.data_ptr(), C, cs, d0, d1, d2,
+                                             t[0], t[1], t[2], _stream(lll)), 'lfgc_idwt_level_cl_f32')
+    return out
+
+
+@_on_device
+def idwt_level_cl_bwd(d_out_cl: torch.Tensor, C: int, filter_rev: torch.Tensor,
+                      d: Sequence[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """d_out_cl (t0,t1,t2,Cs) -> (d_lll (C,d0,d1,d2), d_hf (C,7,d0,d1,d2)): adjoint of idwt_level_cl."""
+    _require_hip(d_out_cl, filter_rev)
+    taps = filter_taps(filter_rev)
+    d = [int(v) for v in d]
+    t0, t1, t2, cs = d_out_cl.shape
+    if not _cl_level_ok(C, d, (t0, t1, t2), taps):
+        return idwt_level_bwd(to_channel_first(d_out_cl, C), filter_rev, d)
+    d_out_cl = _f32c(d_out_cl)
+    d_lll = torch.empty((C, d[0], d[1], d[2]), dtype=torch.float32, device=d_out_cl.device)
+    d_hf = torch.empty((C, 7, d[0], d[1], d[2]), dtype=torch.float32, device=d_out_cl.device)
+    check(_lib.load().lfgc_idwt_level_cl_bwd_f32(d_out_cl.data_ptr(), taps, d_lll.data_ptr(), d_hf.data_ptr(), C, cs,
+                                                 d[0], d[1], d[2], t0, t1, t2, _stream(d_out_cl)),
+          'lfgc_idwt_level_cl_bwd_f32')
+    return d_lll, d_hf
+
+
 def decode_levels(coeffs: Sequence[torch.Tensor], shape_array, filter_rev: torch.Tensor,
                   channel_last: bool) -> torch.Tensor:
     """All IDWT levels (model/Feature_Grid_Model.py:102-108, drop layers already applied by the caller);
-    optionally followed by the conversion to the sampler's channel-last layout."""
+    channel_last: the last level writes the sampler's layout directly."""
     restored = coeffs[0]          # grids smaller than 6 voxels have no wavelet level at all (dwt_max_level = 0)
-    for hf, shape in zip(coeffs[1:], shape_array):
+    n = len(coeffs) - 1
+    for k, (hf, shape) in enumerate(zip(coeffs[1:], shape_array)):
+        if channel_last and k == n - 1:
+            return idwt_level_cl(restored, hf, filter_rev, shape)
         restored = idwt_level(restored, hf, filter_rev, shape)
     return to_channel_last(restored) if channel_last else restored
 
@@ -239,9 +293,14 @@ class DecodeVolumeFn(torch.autograd.Function):
         C = ctx.dims[0][0]
         n_levels = len(ctx.dims) - 1
         grads = [None] * len(ctx.dims)
-        g = to_channel_first(d_out, C) if ctx.channel_last else d_out
+        if ctx.channel_last and n_levels == 0:
+            d_out = to_channel_first(d_out, C)
+        g = d_out
         for lvl in range(n_levels, 0, -1):
-            g, d_hf = idwt_level_bwd(g, ctx.filter_rev, ctx.dims[lvl][2:])
+            if ctx.channel_last and lvl == n_levels:
+                g, d_hf = idwt_level_cl_bwd(g, C, ctx.filter_rev, ctx.dims[lvl][2:])
+            else:
+                g, d_hf = idwt_level_bwd(g, ctx.filter_rev, ctx.dims[lvl][2:])
             grads[lvl] = d_hf
         grads[0] = g
         return (None, None, None) + tuple(grads)

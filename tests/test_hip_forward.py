@@ -109,7 +109,8 @@ def test_wavelet_levels_match_reference(dev, G):
     assert rel_err(dec.cpu().numpy(), g['decoded']) < 1e-6
     dec_cl = ops.decode_levels(coeffs, g['shape_array'], frev, channel_last=True)
     C = g['input'].shape[0]
-    assert dec_cl.shape[-1] == 8 and torch.equal(dec_cl[..., :C].permute(3, 0, 1, 2), dec)
+    # the last level of the channel-last decode is a kernel of its own (different summation order inside the stencil)
+    assert dec_cl.shape[-1] == 8 and rel_err(dec_cl[..., :C].permute(3, 0, 1, 2).cpu().numpy(), g['decoded']) < 1e-6
     assert float(dec_cl[..., C:].abs().max()) == 0.0
     # forward DWT (init path), level by level like encode_volume
     data = torch.from_numpy(g['input']).to(dev)
@@ -148,6 +149,62 @@ def test_wavelet_noncubic_and_adjoint(dev):
     assert xl.shape == (5, 7, 13, 24) and torch.equal(xl[..., :22].permute(3, 0, 1, 2), x)
     assert float(xl[..., 22:].abs().max()) == 0.0
     assert torch.equal(ops.to_channel_first(xl, 22), x)
+
+
+CL_CASES = [   # (C, d, t): channel counts around every stride, ragged planes, every crop the level formula can produce
+    (1, (3, 4, 5), (7, 9, 11)), (5, (6, 7, 9), (13, 15, 19)), (8, (9, 9, 9), (16, 16, 16)), (13, (5, 12, 7), (10, 24, 14)),
+    (16, (17, 17, 17), (32, 32, 32)), (22, (4, 35, 6), (9, 69, 13)), (24, (10, 11, 12), (19, 21, 23)),
+    (30, (8, 9, 40), (17, 18, 81)), (32, (17, 18, 16), (33, 34, 31)), (32, (33, 33, 33), (64, 64, 64)),
+    (3, (1, 1, 1), (2, 3, 4)), (32, (2, 70, 3), (5, 140, 6)),
+]
+
+
+@pytest.mark.parametrize('C,d,t', CL_CASES)
+def test_last_level_channel_last_kernels(dev, C, d, t):
+    """The fused last level (synthesis writing / adjoint reading the channel-last grid) against the channel-first level
+    kernels + the layout conversion, which the tests above pin to the reference fixtures and the oracle's
+    conv_transpose3d.  Different summation order inside the 64-tap stencil: agreement to fp32 rounding."""
+    from latent_feature_grid_compression_amd import ops
+    rng = np.random.default_rng(C * 1000 + d[0])
+    _, frev = R.build_filters(3)
+    frev = frev.to(dev)
+    lll = torch.from_numpy(rng.standard_normal((C,) + d).astype(np.float32)).to(dev)
+    hf = torch.from_numpy(rng.standard_normal((C, 7) + d).astype(np.float32)).to(dev)
+    want = ops.to_channel_last(ops.idwt_level(lll, hf, frev, t))
+    got = ops.idwt_level_cl(lll, hf, frev, t)
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) < 2e-6 * scale
+    cs = got.shape[-1]
+    if cs > C:
+        assert float(got[..., C:].abs().max()) == 0.0
+    g_cl = torch.from_numpy(rng.standard_normal(tuple(t) + (cs,)).astype(np.float32)).to(dev)
+    w_l, w_h = ops.idwt_level_bwd(ops.to_channel_first(g_cl, C), frev, d)
+    g_l, g_h = ops.idwt_level_cl_bwd(g_cl, C, frev, d)
+    s = float(max(w_l.abs().max(), w_h.abs().max()))
+    assert float((g_l - w_l).abs().max()) < 2e-6 * s
+    assert float((g_h - w_h).abs().max()) < 2e-6 * s
+
+
+def test_last_level_channel_last_against_oracle(dev):
+    """... and once directly against the oracle (conv_transpose3d + crop, autograd for the adjoint)."""
+    from latent_feature_grid_compression_amd import ops
+    rng = np.random.default_rng(11)
+    C, d, t = 6, (7, 9, 8), (15, 19, 16)
+    _, frev = R.build_filters(3)
+    data = torch.from_numpy(rng.standard_normal((1, C, 8) + d).astype(np.float32)).requires_grad_(True)
+    ref = R.wavelet_decode(data, t, frev)
+    w = torch.from_numpy(rng.standard_normal(ref.shape).astype(np.float32))
+    ref.backward(w)
+    fd = frev.to(dev)
+    got = ops.idwt_level_cl(data[0, :, 0].detach().to(dev).contiguous(), data[0, :, 1:].detach().to(dev).contiguous(), fd, t)
+    assert rel_err(got[..., :C].permute(3, 0, 1, 2).cpu().numpy(), ref[0].detach().numpy()) < 1e-6
+    g_cl = torch.zeros(tuple(t) + (8,), dtype=torch.float32)
+    g_cl[..., :C] = w[0].permute(1, 2, 3, 0)
+    g_cl[..., C:] = 7.0              # pad channels of the incoming gradient are ignored
+    d_lll, d_hf = ops.idwt_level_cl_bwd(g_cl.to(dev), C, fd, d)
+    assert rel_err(d_lll.cpu().numpy(), data.grad[0, :, 0].numpy()) < 2e-6
+    assert rel_err(d_hf.cpu().numpy(), data.grad[0, :, 1:].numpy()) < 2e-6
 
 
 def test_dense_stencil_for_non_separable_filter(dev):
