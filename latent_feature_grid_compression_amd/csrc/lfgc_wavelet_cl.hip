@@ -54,9 +54,15 @@ __device__ __forceinline__ void cl_load(float& dst, cl_srd r, unsigned lane_off,
     dst = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)lane_off, (int)uniform_off, 0));
 }
 
+// NT: non-temporal (streaming) store.  The synthesis writes whole 64/128-byte runs of a grid nobody reads before the
+// kernel ends; keeping them out of the L2 leaves it to the coefficient lines that neighbouring workgroups share
+// (measured, cfg-5 last level: 205 -> 180 us).  Only for grids that could not stay in the 32 MB of L2 anyway: the cfg-3
+// grid (32 MiB) is sampled right after the decode and the train step is 4 us faster with it cached (0.405 vs 0.409 ms).  The adjoint's stores are 128-byte pieces of unaligned runs that complete
+// each other's lines in the L2: streaming them costs (192 -> 236 us), and so does streaming any of the loads.
+template <bool NT>
 __device__ __forceinline__ void cl_store(float v, cl_srd r, unsigned lane_off, unsigned uniform_off) {
     if ((LFGC_CL_ABLATE & 1) && v != 1.2345e-30f) return;
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)lane_off, (int)uniform_off, 0);   // lane_off >= num_records: dropped
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)lane_off, (int)uniform_off, NT ? 2 : 0);   // lane_off >= num_records: dropped
 }
 
 // Workgroup b works on item (b % 8) * ceil(total / 8) + b / 8 (workgroups are dealt round-robin to the 8 XCDs);
@@ -87,7 +93,7 @@ struct IdwtClArgs {
 // Plane iz of the coefficients is contracted over x and y once (Y[sz][py][px]); its e_z = 0 part completes cell slice
 // jz = iz (added to the carry of plane iz - 1), its e_z = 1 part is the carry for slice iz + 1.
 // Arithmetic role: 32 cells x 2 channels per wave: channel = c0 + 2 wave + lane / 32.
-template <int CW, int CELLS>
+template <int CW, int CELLS, bool NT>
 __global__ __launch_bounds__(CW * CELLS) void idwt_cl_kernel(const IdwtClArgs a) {
     constexpr int CPL = 64 / CELLS;                   // channels per wave in the arithmetic role
     constexpr int CPW = ClShape<CW>::CPW, VOX = ClShape<CW>::VOX;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(CW * CELLS) void idwt_cl_kernel(const IdwtClArgs a)
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
                         const float v = tile[((pz * 4 + p) * CELLS + fcell) * VOX + fch];
-                        cl_store(pad_channel ? 0.0f : v, rout, vo[p], 4u * (unsigned)(oz * slice));
+                        cl_store<NT>(pad_channel ? 0.0f : v, rout, vo[p], 4u * (unsigned)(oz * slice));
                     }
                 }
             }
@@ -372,8 +378,8 @@ __global__ __launch_bounds__(32 * CW) void analysis_cl_kernel(const AnalysisClAr
 #pragma unroll
             for (int sb = 0; sb < 8; ++sb) {
                 const float v = tile[(2 * w + (lane >> 5)) * CHS + sb * kCells + (lane & 31)];
-                if (sb == 0) cl_store(v, rb0, so0, 4u * (unsigned)((c0 + 2 * w) * (int)dvol + iz * plane_cells));
-                else cl_store(v, rbh, soh, 4u * (unsigned)(((c0 + 2 * w) * 7 + sb - 1) * (int)dvol + iz * plane_cells));
+                if (sb == 0) cl_store<false>(v, rb0, so0, 4u * (unsigned)((c0 + 2 * w) * (int)dvol + iz * plane_cells));
+                else cl_store<false>(v, rbh, soh, 4u * (unsigned)(((c0 + 2 * w) * 7 + sb - 1) * (int)dvol + iz * plane_cells));
             }
             buf ^= 1;
         }
@@ -441,18 +447,20 @@ extern "C" int lfgc_idwt_level_cl_f32(const float* lll, const float* hf, const f
     a.zchunk = pick_zchunk(ptiles * a.ngroups, d0 + 1, cw == 32 ? 1 : cw == 16 ? 2 : 4);    // 96 VGPRs: 4 waves per SIMD
     a.nchunks = (d0 + 1 + a.zchunk - 1) / a.zchunk;
     hipStream_t st = (hipStream_t)stream;
+    const bool nt = (long long)t0 * t1 * t2 * channel_stride * 4 > (48LL << 20);       // see cl_store
     if (cw == 32) {
         static bool raised[LFGC_MAX_DEVICES] = {false};     // 67.6 KB of LDS: above the 64 KB default limit
         const int dev = lfgc_current_device();
         if (!raised[dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(idwt_cl_kernel<32, kCells>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(idwt_cl_kernel<32, kCells, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(idwt_cl_kernel<32, kCells, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) return (int)e;
             raised[dev] = true;
         }
-        return launch_cl(idwt_cl_kernel<32, kCells>, 1024, a, lds, st);
+        return nt ? launch_cl(idwt_cl_kernel<32, kCells, true>, 1024, a, lds, st) : launch_cl(idwt_cl_kernel<32, kCells, false>, 1024, a, lds, st);
     }
-    if (cw == 16) return launch_cl(idwt_cl_kernel<16, kCells>, 512, a, lds, st);
-    return launch_cl(idwt_cl_kernel<8, kCells>, 256, a, lds, st);
+    if (cw == 16) return nt ? launch_cl(idwt_cl_kernel<16, kCells, true>, 512, a, lds, st) : launch_cl(idwt_cl_kernel<16, kCells, false>, 512, a, lds, st);
+    return nt ? launch_cl(idwt_cl_kernel<8, kCells, true>, 256, a, lds, st) : launch_cl(idwt_cl_kernel<8, kCells, false>, 256, a, lds, st);
 }
 
 extern "C" int lfgc_idwt_level_cl_bwd_f32(const float* d_out_cl, const float* taps, float* d_lll, float* d_hf,

@@ -68,6 +68,12 @@ echo "== microbenchmarks"
 ./tools/microbench/hwcos_snake > $O/hwcos_snake.log 2>&1
 python3 tools/microbench/idwt_sizes.py > $O/idwt_sizes.log 2>&1; tail -4 $O/idwt_sizes.log
 python3 tests/error_stats.py > $O/fwd_error_stats.log 2>&1
+./tools/microbench/mfma_lds_mix > $O/mfma_lds_mix.log 2>&1
 [ -f tools/microbench/ablate/liblfgc_stamps.so ] && python3 tools/phase_stamps.py run > $O/phase_stamps.log 2>&1
+[ -f tools/microbench/ablate/liblfgc_stamps.so ] && python3 tools/phase_stamps.py run bwd > $O/phase_stamps_bwd.log 2>&1
+[ -f tools/microbench/ablate/liblfgc_ab_base.so ] && python3 tools/ab_wavelet_cl.py run > $O/idwt_cl_ablation.log 2>&1
+echo "== channel-last level kernels: counters"
+bash tools/prof_idwt_cl.sh $1 65 > $O/idwt_cl_pmc.log 2>&1
+rm -rf $O/clpmc_*/ $O/clpmc_*.log
 rm -rf $O/kt_*/ $O/pmc_*/
 ls $O
