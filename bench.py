@@ -201,7 +201,7 @@ def forward_extra(name, device, precision='f16x2', reps=3):
 def train_step_extra(device, precision='f16x2', steps=100, warmup=10):
     """BASELINE config 3 train step (training/training.py:95-138): 32 768 lattice samples of a 255^3 volume -> forward ->
     ground truth + MSE -> backward -> Adam(lr 0.008, torch fused), the whole step captured in one HIP graph and replayed."""
-    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_mse_loss
+    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_mse_loss, mse_unit_grad
     from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
     w = WORKLOADS['headline']
     model = build_model(w, seed=2003, device=device).train()
@@ -214,13 +214,14 @@ def train_step_extra(device, precision='f16x2', steps=100, warmup=10):
     mn_h, mx_h, rs_h = ds.min_idx.tolist(), ds.max_idx.tolist(), ds.vol_res.tolist()
     ds.min_idx, ds.max_idx, ds.scales = ds.min_idx.to(device), ds.max_idx.to(device), ds.scales.to(device)
 
+    unit = mse_unit_grad(device)                       # created outside the capture
+
     def step():
-        flat = torch.randint(0, ds.n_voxels, (n,), device=device)
-        raw, norm = ds.positions_from_flat(flat)
+        raw, norm = ds.sample_positions(n, device, seed=1003)      # draw + positions: one kernel, counter on the device
         norm.requires_grad = True                      # the reference sets requires_grad on positions (training.py:99)
         opt.zero_grad()
         loss = trilinear_mse_loss(model(norm).squeeze(-1), raw, vol, mn_h, mx_h, rs_h)
-        loss.backward()
+        loss.backward(unit)
         opt.step()
         return loss
 

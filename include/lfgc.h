@@ -328,6 +328,17 @@ int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions
 int lfgc_lattice_positions_f32(const int64_t* flat, int64_t n, const int32_t* res, const float* min_idx,
                                const float* max_idx, const float* scales, float* raw, float* norm, lfgc_stream_t stream);
 
+/* The same positions for indices DRAWN by the kernel itself (uniform with replacement, like the randint-on-device sampler
+ * of SURVEY section 8 row f2): flat index i of draw `step` = floor(u * X*Y*Z / 2^64), u = first two words (hi, lo) of
+ * Philox4x32-10 with counter (i lo, i hi, step lo, step hi) and key (seed lo, seed hi).
+ *   state  device int64[2], zeroed ONCE by the caller: [0] = step, advanced by one per call ON THE DEVICE (a captured
+ *          launch therefore draws a fresh batch on every graph replay), [1] = scratch, left at 0
+ *   flat_out  device int64 (N) or NULL: the drawn indices
+ * One launch instead of torch.randint + lfgc_lattice_positions_f32 (+ the generator bookkeeping of a graph replay). */
+int lfgc_lattice_sample_f32(uint64_t seed, int64_t* state, int64_t n, const int32_t* res, const float* min_idx,
+                            const float* max_idx, const float* scales, float* raw, float* norm, int64_t* flat_out,
+                            lfgc_stream_t stream);
+
 /* trilinear_f_interpolation (data/Interpolation.py:8-44), bit-exact: fp32 lattice coordinates, fp64
  * alpha, fp32 lerps in x, y, z order without contraction.
  *   p device (N,3) raw positions; f device (X,Y,Z); min_bb/max_bb/res host float[3]; out device (N). */

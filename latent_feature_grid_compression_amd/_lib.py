@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('LFGC_LIB_PATH') or os.path.join(PKG_DIR, 'liblfgc.so')   # override: diagnostics builds only
@@ -81,6 +81,8 @@ SIGNATURES = {
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'lfgc_lattice_positions_f32': (c_int, [c_void_p, c_int64, POINTER(c_int32), POINTER(c_float), POINTER(c_float),
                                            POINTER(c_float), c_void_p, c_void_p, c_void_p]),
+    'lfgc_lattice_sample_f32': (c_int, [c_uint64, c_void_p, c_int64, POINTER(c_int32), POINTER(c_float), POINTER(c_float),
+                                        POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p]),
     'lfgc_deviation_partial_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     'lfgc_debug_trig_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     'lfgc_debug_hwsin_f32': (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),

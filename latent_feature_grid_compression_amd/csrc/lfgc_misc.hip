@@ -188,6 +188,61 @@ __device__ __forceinline__ double lfgc_fwd_image_divisor(int l) {
     return l == 0 ? 3.14159265358979323846 : 3.14159265358979323846 * LFGC_ACT_SCALE;
 }
 
+// The draw of a train step and its positions in ONE kernel (the data/IndexDataset.py:90-96 sampler with the indices
+// drawn on the device): flat index i of draw number `step` = floor(u64 * n_voxels / 2^64) with
+// u64 = the first two words of Philox4x32-10(counter = (i, step), key = seed) -- counter-based, so a replayed HIP graph
+// draws a new batch every replay: `state[0]` (device) holds the step; the last workgroup to finish advances it
+// (every workgroup has read it by then: ticket in state[1], left at 0).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned* r0, unsigned* r1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    *r0 = c0; *r1 = c1;
+}
+
+struct LatticeSampleArgs {
+    LatticeArgs l;                 // l.flat unused
+    long long* flat_out;           // optional
+    unsigned long long* state;     // [0] step, [1] ticket
+    unsigned long long seed, n_voxels;
+};
+
+__global__ __launch_bounds__(256) void lattice_sample_kernel(const LatticeSampleArgs a) {
+    const unsigned long long step = __hip_atomic_load(a.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.l.n) {
+        unsigned r0, r1;
+        philox4x32_10((unsigned)i, (unsigned)((unsigned long long)i >> 32), (unsigned)step, (unsigned)(step >> 32),
+                      (unsigned)a.seed, (unsigned)(a.seed >> 32), &r0, &r1);
+        const long long f = (long long)__umul64hi(((unsigned long long)r0 << 32) | r1, a.n_voxels);
+        if (a.flat_out) a.flat_out[i] = f;
+        const long long yz = (long long)a.l.Y * a.l.Z;
+        const float q0 = (float)(f / yz), q1 = (float)((f / a.l.Z) % a.l.Y), q2 = (float)(f % a.l.Z);
+        auto nrm = [](float r, float mn, float mx, float sc) {
+            const float q = __fdiv_rn(__fsub_rn(r, mn), __fsub_rn(mx, mn));
+            return __fmul_rn(sc, __fadd_rn(__fmul_rn(2.0f, q), -1.0f));
+        };
+        a.l.raw[3 * i + 0] = q0; a.l.raw[3 * i + 1] = q1; a.l.raw[3 * i + 2] = q2;
+        a.l.norm[3 * i + 0] = nrm(q0, a.l.min0, a.l.max0, a.l.sc0);
+        a.l.norm[3 * i + 1] = nrm(q1, a.l.min1, a.l.max1, a.l.sc1);
+        a.l.norm[3 * i + 2] = nrm(q2, a.l.min2, a.l.max2, a.l.sc2);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = __hip_atomic_fetch_add(a.state + 1, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1) {
+            __hip_atomic_store(a.state + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.state, step + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 __device__ __forceinline__ int lfgc_pow2_exponent_for(float m) {
     int e = 0;
     if (m > 0.0f && m < INFINITY) { (void)frexpf(m, &e); e = 14 - e; }    // m = f * 2^e', f in [0.5,1) -> m * 2^(14-e') in [2^13, 2^14)
@@ -397,6 +452,26 @@ extern "C" int lfgc_lattice_positions_f32(const int64_t* flat, int64_t n, const 
     a.max0 = max_idx[0]; a.max1 = max_idx[1]; a.max2 = max_idx[2];
     a.sc0 = scales[0]; a.sc1 = scales[1]; a.sc2 = scales[2];
     hipLaunchKernelGGL(lattice_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    LFGC_HIP_CHECK_LAUNCH();
+    return LFGC_OK;
+}
+
+extern "C" int lfgc_lattice_sample_f32(uint64_t seed, int64_t* state, int64_t n, const int32_t* res, const float* min_idx,
+                                       const float* max_idx, const float* scales, float* raw, float* norm, int64_t* flat_out,
+                                       lfgc_stream_t stream) {
+    if (!state || !res || !min_idx || !max_idx || !scales || !raw || !norm) return LFGC_E_NULL;
+    if (n < 0 || res[0] < 1 || res[1] < 1 || res[2] < 1) return LFGC_E_SHAPE;
+    if (n == 0) return LFGC_OK;
+    LatticeSampleArgs a;
+    a.l.flat = nullptr; a.l.raw = raw; a.l.norm = norm; a.l.n = n;
+    a.l.Y = res[1]; a.l.Z = res[2];
+    a.l.min0 = min_idx[0]; a.l.min1 = min_idx[1]; a.l.min2 = min_idx[2];
+    a.l.max0 = max_idx[0]; a.l.max1 = max_idx[1]; a.l.max2 = max_idx[2];
+    a.l.sc0 = scales[0]; a.l.sc1 = scales[1]; a.l.sc2 = scales[2];
+    a.flat_out = reinterpret_cast<long long*>(flat_out);
+    a.state = reinterpret_cast<unsigned long long*>(state);
+    a.seed = seed; a.n_voxels = (unsigned long long)res[0] * (unsigned long long)res[1] * (unsigned long long)res[2];
+    hipLaunchKernelGGL(lattice_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }

@@ -18,6 +18,7 @@
 // write the two halves of the same 128-byte lines) and neighbouring tiles (they share coefficient rows / source voxels)
 // run on the same XCD and meet in its L2.
 #include "lfgc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -439,7 +440,8 @@ extern "C" int lfgc_idwt_level_cl_f32(const float* lll, const float* hf, const f
     // 32 channels on a large plane: one workgroup of 16 waves writes whole 128-byte lines (d = 65: 197 vs 203 us); on a
     // small one two 8-wave groups balance better (d = 33: 26.5 vs 28.7 us).  24 channels: three groups of 8.
     const long long ptiles = ((long long)(d1 + 1) * (d2 + 1) + kCells - 1) / kCells;
-    const int cw = channel_stride == 32 ? (ptiles >= 96 ? 32 : 16) : channel_stride == 16 ? 16 : 8;
+    int cw = channel_stride == 32 ? (ptiles >= 96 ? 32 : 16) : channel_stride == 16 ? 16 : 8;
+    if (const char* e = getenv("LFGC_CL_CW")) { const int v = atoi(e); if ((v == 8 || v == 16 || v == 32) && channel_stride % v == 0) cw = v; }   // diagnostics
     a.ngroups = channel_stride / cw;
     if (ptiles * a.ngroups > 0x0fffffffLL) return LFGC_E_UNSUPPORTED;
     a.ptiles = (int)ptiles;
@@ -447,7 +449,8 @@ extern "C" int lfgc_idwt_level_cl_f32(const float* lll, const float* hf, const f
     a.zchunk = pick_zchunk(ptiles * a.ngroups, d0 + 1, cw == 32 ? 1 : cw == 16 ? 2 : 4);    // 96 VGPRs: 4 waves per SIMD
     a.nchunks = (d0 + 1 + a.zchunk - 1) / a.zchunk;
     hipStream_t st = (hipStream_t)stream;
-    const bool nt = (long long)t0 * t1 * t2 * channel_stride * 4 > (48LL << 20);       // see cl_store
+    bool nt = (long long)t0 * t1 * t2 * channel_stride * 4 > (48LL << 20);             // see cl_store
+    if (const char* e = getenv("LFGC_CL_NT")) nt = e[0] == '1';                         // diagnostics
     if (cw == 32) {
         static bool raised[LFGC_MAX_DEVICES] = {false};     // 67.6 KB of LDS: above the 64 KB default limit
         const int dev = lfgc_current_device();

@@ -73,6 +73,21 @@ class IndexDataset(torch.utils.data.Dataset):
             return ops.lattice_positions(flat_idx, self.vol_res_touple, mn, mx, sc)
         return self.positions_for(self.lattice_from_flat(flat_idx))
 
+    def sample_positions(self, n: int, device, seed: int = 0):
+        """(raw, normalised) positions of `n` voxels drawn uniformly with replacement ON the device, draw and positions in
+        one HIP kernel (ops.lattice_sample).  The draw counter is device state of this dataset: successive calls -- and
+        successive replays of a captured call -- give successive batches of the stream selected by `seed`."""
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        st = getattr(self, '_sample_state', None)
+        if st is None or st.device != device:
+            st = self._sample_state = torch.zeros(2, dtype=torch.int64, device=device)
+        if getattr(self, '_host_bounds', None) is None:
+            self._host_bounds = (self.min_idx.cpu().tolist(), self.max_idx.cpu().tolist(), self.scales.cpu().tolist())
+        mn, mx, sc = self._host_bounds
+        return ops.lattice_sample(st, n, seed, self.vol_res_touple, mn, mx, sc)
+
     def __len__(self):
         return self.n_voxels
 
@@ -99,3 +114,8 @@ class DeviceLatticeSampler:
     def sample(self, n: int, generator=None):
         flat = torch.randint(0, self.n_voxels, (int(n),), device=self.device, generator=generator)
         return self.ds.positions_from_flat(flat)
+
+    def sample_fused(self, n: int, seed: int = 0):
+        """The same in one kernel: the indices are drawn by a counter-based generator inside the kernel that forms the
+        positions (IndexDataset.sample_positions); two launches and torch's per-replay generator bookkeeping less."""
+        return self.ds.sample_positions(n, self.device, seed)

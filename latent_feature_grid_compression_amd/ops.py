@@ -872,6 +872,9 @@ class GtMseLossFn(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, g):
         (d_pred,) = ctx.saved_tensors
+        unit = _UNIT_GRADS.get(g.device)
+        if unit is not None and g.data_ptr() == unit.data_ptr():      # unit_grad(): known to be 1.0
+            return d_pred.view(ctx.shape), None, None, None, None, None
         return (d_pred * g).view(ctx.shape), None, None, None, None, None
 
 
@@ -892,6 +895,44 @@ def lattice_positions(flat: torch.Tensor, res, min_idx, max_idx, scales) -> Tupl
     check(_lib.load().lfgc_lattice_positions_f32(flat.data_ptr(), n, r3, f3(min_idx), f3(max_idx), f3(scales),
                                                  raw.data_ptr(), norm.data_ptr(), _stream(flat)), 'lfgc_lattice_positions_f32')
     return raw, norm
+
+
+@_on_device
+def lattice_sample(state: torch.Tensor, n: int, seed: int, res, min_idx, max_idx, scales,
+                   want_flat: bool = False):
+    """(raw (N,3), norm (N,3)[, flat (N) int64]) for N voxel indices drawn uniformly (with replacement) by the kernel
+    itself: lfgc_lattice_sample_f32.  `state`: device int64[2], zeroed once by the caller and then left alone -- the
+    draw counter lives in it and advances on the device, so a captured call draws a new batch on every graph replay."""
+    _require_hip(state)
+    if state.dtype != torch.int64 or state.numel() != 2 or not state.is_contiguous():
+        raise ValueError('state must be a contiguous int64 tensor of 2 elements')
+    n = int(n)
+    raw = torch.empty((n, 3), dtype=torch.float32, device=state.device)
+    norm = torch.empty((n, 3), dtype=torch.float32, device=state.device)
+    flat = torch.empty(n, dtype=torch.int64, device=state.device) if want_flat else None
+    f3 = lambda v: (ctypes.c_float * 3)(*[float(x) for x in (v.tolist() if hasattr(v, 'tolist') else v)])
+    r3 = (ctypes.c_int32 * 3)(*[int(x) for x in res])
+    check(_lib.load().lfgc_lattice_sample_f32(int(seed) & 0xFFFFFFFFFFFFFFFF, state.data_ptr(), n, r3, f3(min_idx), f3(max_idx),
+                                              f3(scales), raw.data_ptr(), norm.data_ptr(),
+                                              flat.data_ptr() if want_flat else None, _stream(state)),
+          'lfgc_lattice_sample_f32')
+    return (raw, norm, flat) if want_flat else (raw, norm)
+
+
+# Gradient seed of a scalar loss that GtMseLossFn.backward recognises by identity and does not multiply by: one fill
+# and one elementwise launch less per train step than `loss.backward()` (autograd's ones_like + `d_pred * g`).  Read-only.
+_UNIT_GRADS = {}
+
+
+def unit_grad(device) -> torch.Tensor:
+    """0-d fp32 tensor holding 1.0 on `device` (cached; create it before capturing a graph): `loss.backward(unit_grad(dev))`."""
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    t = _UNIT_GRADS.get(device)
+    if t is None:
+        t = _UNIT_GRADS[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
 
 
 @_on_device

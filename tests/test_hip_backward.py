@@ -201,6 +201,96 @@ def test_device_lattice_sampler_matches_index_dataset(dev):
     assert torch.equal(raw_k.cpu(), raw_t) and torch.equal(norm_k.cpu(), norm_t)
 
 
+def _philox4x32_10(c, k):
+    """numpy restatement of Philox4x32-10 (Salmon et al., SC'11; the generator include/lfgc.h names for
+    lfgc_lattice_sample_f32): c (n,4) uint32 counters, k (2,) uint32 key -> (n,4) uint32."""
+    c = c.astype(np.uint64).copy()
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[:, 0]
+        p1 = np.uint64(0xCD9E8D57) * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & m32
+        c = np.stack([n0, p1 & m32, n2, p0 & m32], 1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return c.astype(np.uint32)
+
+
+def test_fused_lattice_sampler(dev):
+    """Row f2, one-kernel form: the indices the kernel draws are the documented Philox stream (checked against the numpy
+    restatement above, incl. the published known-answer vector), the positions are IndexDataset's for those indices, the
+    draw counter advances on the device -- also across replays of a captured launch."""
+    from latent_feature_grid_compression_amd import ops
+    from latent_feature_grid_compression_amd.data.IndexDataset import DeviceLatticeSampler, IndexDataset
+    # known-answer test of the restatement (Random123 kat_vectors: philox4x32-10, all-ones counter and key)
+    kat = _philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint32))[0]
+    assert [int(v) for v in kat] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    shape = (255, 255, 255)
+    ds = IndexDataset(shape, 16, build_index_table=False)
+    nvox = 255 ** 3
+    n, seed = 40000, 0x1234_5678_9ABC_DEF1
+    state = torch.zeros(2, dtype=torch.int64, device=dev)
+    mn, mx, sc = ds.min_idx.tolist(), ds.max_idx.tolist(), ds.scales.tolist()
+    for step in range(3):
+        raw, norm, flat = ops.lattice_sample(state, n, seed, shape, mn, mx, sc, want_flat=True)
+        assert state.cpu().tolist() == [step + 1, 0]
+        ctr = np.zeros((n, 4), np.uint32)
+        ctr[:, 0] = np.arange(n)
+        ctr[:, 2] = step
+        r = _philox4x32_10(ctr, np.array([seed & 0xFFFFFFFF, seed >> 32], np.uint32))
+        u = [(int(a) << 32) | int(b) for a, b in zip(r[:, 0], r[:, 1])]
+        want = np.array([(x * nvox) >> 64 for x in u], np.int64)
+        assert np.array_equal(flat.cpu().numpy(), want)
+        raw_t, norm_t = ds.positions_for(ds.lattice_from_flat(flat.cpu()))
+        assert torch.equal(raw.cpu(), raw_t) and torch.equal(norm.cpu(), norm_t)
+    # uniform over the volume: 64 equal slabs of the flat index range, 40 000 draws -> chi^2 with 63 degrees of freedom
+    counts = np.bincount((flat.cpu().numpy() * 64 // nvox), minlength=64)
+    chi2 = float(((counts - n / 64) ** 2 / (n / 64)).sum())
+    assert chi2 < 120.0, chi2                          # P(chi2_63 > 120) ~ 2e-5
+    # captured launch: every replay draws the next batch
+    smp = DeviceLatticeSampler((20, 21, 22), dev)
+    smp.sample_fused(256, seed=7)                      # creates the device state outside the capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        smp.sample_fused(256, seed=7)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        raw_g, _ = smp.sample_fused(256, seed=7)
+    seen = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        seen.append(raw_g.cpu().clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    assert smp.ds._sample_state.cpu().tolist() == [5, 0]
+    r = seen[2]
+    assert torch.equal(r, r.round()) and float(r.min()) >= 0 and all(float(r[:, a].max()) <= (20, 21, 22)[a] - 1 for a in range(3))
+
+
+def test_unit_grad_seed_skips_nothing_but_the_multiply(dev):
+    """loss.backward(mse_unit_grad(dev)) gives the gradients of loss.backward() bit for bit."""
+    from latent_feature_grid_compression_amd.data.Interpolation import trilinear_mse_loss, mse_unit_grad
+    rng = np.random.default_rng(3)
+    vol = torch.from_numpy(rng.uniform(-1, 1, (9, 10, 11)).astype(np.float32)).to(dev)
+    p = torch.from_numpy(rng.uniform(0, 8, (500, 3)).astype(np.float32)).to(dev)
+    mn, mx, rs = [0.0, 0.0, 0.0], [8.0, 9.0, 10.0], [9.0, 10.0, 11.0]
+    grads = []
+    for seed in (None, mse_unit_grad(dev), torch.full((), 1.0, device=dev)):
+        pred = torch.from_numpy(rng.standard_normal(500).astype(np.float32)).to(dev).requires_grad_(True) if not grads \
+            else grads[0][1].detach().clone().requires_grad_(True)
+        loss = trilinear_mse_loss(pred, p, vol, mn, mx, rs)
+        loss.backward() if seed is None else loss.backward(seed)
+        grads.append((pred.grad.clone(), pred))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][0], grads[2][0])
+    pred = grads[0][1].detach().clone().requires_grad_(True)
+    trilinear_mse_loss(pred, p, vol, mn, mx, rs).backward(torch.full((), 3.0, device=dev))
+    assert torch.allclose(pred.grad, 3.0 * grads[0][0], rtol=1e-6, atol=0)
+
+
 class _ScaleDrop(torch.nn.Module):
     """Minimal pruning layer with the reference's DropoutLayer interface (model/Dropout_Layer.py:4-39): one learnable
     multiplicative factor per coefficient position, broadcast over channels -- what SmallifyDropout.forward does
