@@ -156,6 +156,7 @@ CL_CASES = [   # (C, d, t): channel counts around every stride, ragged planes, e
     (16, (17, 17, 17), (32, 32, 32)), (22, (4, 35, 6), (9, 69, 13)), (24, (10, 11, 12), (19, 21, 23)),
     (30, (8, 9, 40), (17, 18, 81)), (32, (17, 18, 16), (33, 34, 31)), (32, (33, 33, 33), (64, 64, 64)),
     (3, (1, 1, 1), (2, 3, 4)), (32, (2, 70, 3), (5, 140, 6)),
+    (40, (5, 6, 7), (11, 13, 15)),      # C > 32: the wrappers fall back to level + layout conversion
 ]
 
 

@@ -68,6 +68,17 @@ def test_pure_host_entry_points(built_lib):
     assert lib.lfgc_penalty_sums_f32(None, 0, None, None) == -1 and lib.lfgc_drop_apply_f32(None, None, 0.0, None, 1, 1, None) == -1
     assert lib.lfgc_forward_f32(ctypes.byref(ok), None, None, 1, 1, 1, None, 0, 0, None, None, None, None) == -1
     assert lib.lfgc_gt_interp_f32(None, None, None, None, None, 0, 1, 1, 1, None, None) == -1
+    # channel-last level: NULL, then the shapes it hands back to the two-kernel form (-3) -- dense stencil (no taps),
+    # a channel stride that is not C rounded up to 8 (-2), arrays of 2^30 bytes and more
+    taps = (ctypes.c_float * 8)(*[0.5] * 8)
+    one = ctypes.c_void_p(16)                            # any non-NULL address: nothing is launched on these paths
+    assert lib.lfgc_idwt_level_cl_f32(None, None, taps, None, 1, 8, 1, 1, 1, 1, 1, 1, None) == -1
+    assert lib.lfgc_idwt_level_cl_f32(one, one, None, one, 4, 8, 3, 3, 3, 6, 6, 6, None) == -3
+    assert lib.lfgc_idwt_level_cl_f32(one, one, taps, one, 4, 16, 3, 3, 3, 6, 6, 6, None) == -2
+    assert lib.lfgc_idwt_level_cl_f32(one, one, taps, one, 32, 32, 200, 200, 200, 400, 400, 400, None) == -3
+    assert lib.lfgc_idwt_level_cl_bwd_f32(one, None, one, one, 4, 8, 3, 3, 3, 6, 6, 6, None) == -3
+    assert lib.lfgc_idwt_level_cl_bwd_f32(one, taps, one, one, 4, 8, 3, 3, 3, 9, 6, 6, None) == -2     # t > 2 d + 2
+    assert lib.lfgc_lattice_sample_f32(0, None, 1, None, None, None, None, None, None, None, None) == -1
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
