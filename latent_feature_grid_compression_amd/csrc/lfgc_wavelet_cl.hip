@@ -4,8 +4,8 @@
 // so that decode_volume() needs no layout conversion pass (lfgc_grid_layout_f32) on either direction.  Separable
 // filter banks only (`taps`); the dense-stencil path keeps the channel-first kernels + the conversion.
 //
-// Both kernels have one shape.  A workgroup owns 32 consecutive cells of the flattened (y,x) plane, a group of CW = 16
-// (or 8) channels, and walks a chunk of z steps.  The coefficient side is channel-first (contiguous along the cells), the
+// Both kernels have one shape.  A workgroup owns 32 consecutive cells of the flattened (y,x) plane, a group of CW = 32,
+// 16 or 8 channels (CW / 2 waves), and walks a chunk of z steps.  The coefficient side is channel-first (contiguous along the cells), the
 // grid side channel-last (contiguous along the channels), so the arithmetic runs with the lanes along whichever side is
 // being READ -- straight from global memory, neighbouring lanes on neighbouring addresses, the 4x reuse between
 // neighbouring cells served by L1/L2 -- and the 8 results per (cell, channel) go through an LDS tile that is read back
@@ -24,7 +24,7 @@ namespace {
 
 constexpr int kCells = 32;           // plane cells per workgroup
 
-template <int CW> struct ClShape {   // CW: channels per workgroup (8 or 16)
+template <int CW> struct ClShape {   // CW: channels per workgroup (8, 16; synthesis also 32)
     static constexpr int NW = CW / 2;                    // waves per workgroup
     static constexpr int CPW = 64 / CW;                  // voxels / cells per wave instruction with the lanes along channels
     static constexpr int VOX = CW + 1;                   // synthesis tile [8 parities][32 cells][CW + 1]
@@ -43,7 +43,7 @@ template <int CW> struct ClShape {   // CW: channels per workgroup (8 or 16)
 constexpr unsigned kOutside = 0x40000000u;            // arrays on these paths are < 2^30 bytes (host check)
 typedef __amdgpu_buffer_rsrc_t cl_srd;
 #ifndef LFGC_CL_ABLATE
-#define LFGC_CL_ABLATE 0             // diagnostics (tools/ab_wavelet_cl.py): 1 no global stores, 2 no global loads, 4 no LDS tile
+#define LFGC_CL_ABLATE 0             // diagnostics (tools/ab_wavelet_cl.py): 1 no global stores, 2 no global loads
 #endif
 
 __device__ __forceinline__ cl_srd cl_make_srd(const void* p, unsigned bytes) {
@@ -57,9 +57,11 @@ __device__ __forceinline__ void cl_load(float& dst, cl_srd r, unsigned lane_off,
 
 // NT: non-temporal (streaming) store.  The synthesis writes whole 64/128-byte runs of a grid nobody reads before the
 // kernel ends; keeping them out of the L2 leaves it to the coefficient lines that neighbouring workgroups share
-// (measured, cfg-5 last level: 205 -> 180 us).  Only for grids that could not stay in the 32 MB of L2 anyway: the cfg-3
-// grid (32 MiB) is sampled right after the decode and the train step is 4 us faster with it cached (0.405 vs 0.409 ms).  The adjoint's stores are 128-byte pieces of unaligned runs that complete
-// each other's lines in the L2: streaming them costs (192 -> 236 us), and so does streaming any of the loads.
+// (measured, cfg-5 last level: 205 -> 180 us; only with whole lines, i.e. 32-channel workgroups: 64- and 32-byte
+// pieces get slower).  Only for grids that could not stay in the 32 MB of L2 anyway: the cfg-3 grid (32 MiB) is sampled
+// right after the decode and the train step is 4 us faster with it cached (0.405 vs 0.409 ms).  The adjoint's stores
+// are 128-byte pieces of unaligned runs that complete each other's lines in the L2: streaming them costs (192 ->
+// 236 us), and so does streaming any of the loads.
 template <bool NT>
 __device__ __forceinline__ void cl_store(float v, cl_srd r, unsigned lane_off, unsigned uniform_off) {
     if ((LFGC_CL_ABLATE & 1) && v != 1.2345e-30f) return;
@@ -265,122 +267,148 @@ struct AnalysisClArgs {
 // Adjoint: band_s[c][i] = sum_t src[2 i + t - lo][c] F_s[t].  Step iz reads the source planes 2 iz - lo0 + {2, 3},
 // contracts each over x and y (P[sy][sx]) and combines them with the two planes carried from step iz - 1.
 // Arithmetic role: lanes = CW channels x CPW cells; cell = wave * CPW + lane / CW.
-template <int CW>
+template <int CW, int NG>          // NG: cell groups of 32 per workgroup (the channel-first runs it writes are 128 NG bytes)
 __global__ __launch_bounds__(32 * CW) void analysis_cl_kernel(const AnalysisClArgs a) {
-    constexpr int NW = ClShape<CW>::NW, CPW = ClShape<CW>::CPW, CHS = ClShape<CW>::CHS;
+    constexpr int CPW = ClShape<CW>::CPW, CELLS = kCells * NG, CHS = 8 * CELLS + 1;
     constexpr int TILE = CW * CHS;
-    extern __shared__ __attribute__((aligned(16))) float s_tile[];      // [2][TILE]
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];      // [2][TILE]: [channel][band][cell] + 1
     int pt, cg, zc;
     if (!cl_work_item(a.ptiles, a.ngroups, a.nchunks, &pt, &cg, &zc)) return;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int plane_cells = a.d1 * a.d2;
-    const int f0 = pt * kCells;
+    const int f0 = pt * CELLS;
     const int c0 = cg * CW;
     const int iz_begin = zc * a.zchunk, iz_end = min(iz_begin + a.zchunk, a.d0);
-    const long long dvol = (long long)plane_cells * a.d0;
+    const int dvol = plane_cells * a.d0;              // C * 7 * dvol * 4 < 2^30 (host check)
     const int nplane = a.n1 * a.n2 * a.cs;            // n0 * nplane * 4 < 2^30 (host check)
 
+    // arithmetic role: lanes = CW channels x CPW cells; cell of group g = 32 g + wave * CPW + lane / CW
     const int ch = lane & (CW - 1), cslot = w * CPW + lane / CW;
-    unsigned ro[4], co[4];         // byte offsets of row ty / column tx (+ channel) inside a source plane; kOutside when outside
-    {
-        const int f = f0 + cslot;
+    unsigned ro[NG][4], co[NG][4]; // byte offsets of row ty / column tx (+ channel) inside a source plane; kOutside when outside
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int f = f0 + g * kCells + cslot;
         const bool live = f < plane_cells && c0 + ch < a.C;
         const int fc = min(f, plane_cells - 1);
         const int iy = fc / a.d2, ix = fc - iy * a.d2;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int uy = 2 * iy + t - a.lo1, ux = 2 * ix + t - a.lo2;
-            ro[t] = (live && uy >= 0 && uy < a.n1) ? 4u * (unsigned)(uy * a.n2 * a.cs) : kOutside;
-            co[t] = (ux >= 0 && ux < a.n2) ? 4u * (unsigned)(ux * a.cs + c0 + ch) : kOutside;
+            ro[g][t] = (live && uy >= 0 && uy < a.n1) ? 4u * (unsigned)(uy * a.n2 * a.cs) : kOutside;
+            co[g][t] = (ux >= 0 && ux < a.n2) ? 4u * (unsigned)(ux * a.cs + c0 + ch) : kOutside;
         }
     }
     const cl_srd rs = cl_make_srd(a.src, (unsigned)(a.n0 * nplane * 4));
 
-    // store role: lane = (cell, channel parity)
+    // store role: NG == 1: lane = (cell, channel parity), one instruction per band; NG >= 2: lane = cell, one instruction per
+    // band, channel and 64 cells
     unsigned so0, soh;
-    {
+    if (NG == 1) {
         const int sf = f0 + (lane & 31), half = lane >> 5;
         const bool ok = sf < plane_cells && c0 + 2 * w + half < a.C;
-        so0 = ok ? 4u * (unsigned)(half * (int)dvol + sf) : kOutside;
-        soh = ok ? 4u * (unsigned)(half * 7 * (int)dvol + sf) : kOutside;
+        so0 = ok ? 4u * (unsigned)(half * dvol + sf) : kOutside;
+        soh = ok ? 4u * (unsigned)(half * 7 * dvol + sf) : kOutside;
+    } else {
+        so0 = soh = 4u * (unsigned)(f0 + lane);
     }
-    const cl_srd rb0 = cl_make_srd(a.band0, (unsigned)(a.C * (int)dvol * 4));
-    const cl_srd rbh = cl_make_srd(a.bandh, (unsigned)(a.C * 7 * (int)dvol * 4));
+    const cl_srd rb0 = cl_make_srd(a.band0, (unsigned)(a.C * dvol * 4));
+    const cl_srd rbh = cl_make_srd(a.bandh, (unsigned)(a.C * 7 * dvol * 4));
 
-    float R[32];                   // [plane k][ty*4+tx]
-    float carry[2][4];             // [plane tz = 0, 1 of the next step][sy*2+sx]
+    float R[32];                   // [plane k][ty*4+tx] of the cell group in flight
+    float carry[NG][2][4];         // [group][plane tz = 0, 1 of the next step][sy*2+sx]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) carry[i >> 2][i & 3] = 0.0f;
+    for (int i = 0; i < 8 * NG; ++i) carry[i >> 3][(i >> 2) & 1][i & 3] = 0.0f;
 
     auto plane_in = [&](int iz, int k) { const int uz = 2 * iz - a.lo0 + 2 + k; return uz >= 0 && uz < a.n0; };
-    auto issue = [&](int iz) {                         // source planes 2 iz - lo0 + {2,3} (outside the level: not read, P = 0)
+    auto issue = [&](int iz, int g) {                  // source planes 2 iz - lo0 + {2,3} (outside the level: not read, P = 0)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (plane_in(iz, k)) {
                 const unsigned sp = 4u * (unsigned)((2 * iz - a.lo0 + 2 + k) * nplane);
 #pragma unroll
-                for (int t = 0; t < 16; ++t) cl_load(R[k * 16 + t], rs, ro[t >> 2] + co[t & 3], sp);
+                for (int t = 0; t < 16; ++t) cl_load(R[k * 16 + t], rs, ro[g][t >> 2] + co[g][t & 3], sp);
             }
         }
     };
 
     int iz = iz_begin - 1;
-    issue(iz);
+    issue(iz, 0);
     int buf = 0;
 #pragma unroll 1
     for (; iz < iz_end; ++iz) {
         const bool emit = iz >= iz_begin;
         float* tile = s_tile + buf * TILE;
-        float P[2][4];                                            // new planes tz = 2, 3: [sy*2+sx]
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (plane_in(iz, k)) {
-                float X[4][2];
+        for (int g = 0; g < NG; ++g) {
+            float P[2][4];                                        // new planes tz = 2, 3: [sy*2+sx]
 #pragma unroll
-                for (int ty = 0; ty < 4; ++ty) {
-                    float x0 = 0.0f, x1 = 0.0f;
+            for (int k = 0; k < 2; ++k) {
+                if (plane_in(iz, k)) {
+                    float X[4][2];
 #pragma unroll
-                    for (int tx = 0; tx < 4; ++tx) {
-                        x0 = __builtin_fmaf(R[k * 16 + ty * 4 + tx], a.taps[tx], x0);
-                        x1 = __builtin_fmaf(R[k * 16 + ty * 4 + tx], a.taps[4 + tx], x1);
+                    for (int ty = 0; ty < 4; ++ty) {
+                        float x0 = 0.0f, x1 = 0.0f;
+#pragma unroll
+                        for (int tx = 0; tx < 4; ++tx) {
+                            x0 = __builtin_fmaf(R[k * 16 + ty * 4 + tx], a.taps[tx], x0);
+                            x1 = __builtin_fmaf(R[k * 16 + ty * 4 + tx], a.taps[4 + tx], x1);
+                        }
+                        X[ty][0] = x0; X[ty][1] = x1;
                     }
-                    X[ty][0] = x0; X[ty][1] = x1;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        float t = 0.0f;
+#pragma unroll
+                        for (int ty = 0; ty < 4; ++ty) t = __builtin_fmaf(X[ty][s4 & 1], a.taps[(s4 >> 1) * 4 + ty], t);
+                        P[k][s4] = t;
+                    }
+                } else {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) P[k][s4] = 0.0f;
                 }
+            }
+            // R is free: the next group's / step's planes fly under the rest of this one
+            if (g + 1 < NG) issue(iz, g + 1);
+            else if (iz + 1 < iz_end) issue(iz + 1, 0);
+            if (emit) {
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    float t = 0.0f;
-#pragma unroll
-                    for (int ty = 0; ty < 4; ++ty) t = __builtin_fmaf(X[ty][s4 & 1], a.taps[(s4 >> 1) * 4 + ty], t);
-                    P[k][s4] = t;
+                for (int sb = 0; sb < 8; ++sb) {
+                    const int s4 = sb & 3, sz = sb >> 2;
+                    float t = carry[g][0][s4] * a.taps[sz * 4 + 0];
+                    t = __builtin_fmaf(carry[g][1][s4], a.taps[sz * 4 + 1], t);
+                    t = __builtin_fmaf(P[0][s4], a.taps[sz * 4 + 2], t);
+                    t = __builtin_fmaf(P[1][s4], a.taps[sz * 4 + 3], t);
+                    tile[ch * CHS + sb * CELLS + g * kCells + cslot] = t;
                 }
-            } else {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) P[k][s4] = 0.0f;
             }
-        }
-        if (iz + 1 < iz_end) issue(iz + 1);                       // R is free: the next planes fly under the rest of the step
-        if (emit) {
 #pragma unroll
-            for (int sb = 0; sb < 8; ++sb) {
-                const int s4 = sb & 3, sz = sb >> 2;
-                float t = carry[0][s4] * a.taps[sz * 4 + 0];
-                t = __builtin_fmaf(carry[1][s4], a.taps[sz * 4 + 1], t);
-                t = __builtin_fmaf(P[0][s4], a.taps[sz * 4 + 2], t);
-                t = __builtin_fmaf(P[1][s4], a.taps[sz * 4 + 3], t);
-                tile[ch * CHS + sb * kCells + cslot] = t;
-            }
+            for (int s4 = 0; s4 < 4; ++s4) { carry[g][0][s4] = P[0][s4]; carry[g][1][s4] = P[1][s4]; }
         }
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { carry[0][s4] = P[0][s4]; carry[1][s4] = P[1][s4]; }
         if (emit) {
             __syncthreads();
-            // store role: 32 cells x 2 channels per instruction, instruction = band; this wave's channels are {2 w, 2 w + 1}
+            // store role: this wave's channels are {2 w, 2 w + 1}; whole 128 NG-byte runs of one (channel, band) per half wave / wave
+            const unsigned zoff = (unsigned)(iz * plane_cells);
 #pragma unroll
             for (int sb = 0; sb < 8; ++sb) {
-                const float v = tile[(2 * w + (lane >> 5)) * CHS + sb * kCells + (lane & 31)];
-                if (sb == 0) cl_store<false>(v, rb0, so0, 4u * (unsigned)((c0 + 2 * w) * (int)dvol + iz * plane_cells));
-                else cl_store<false>(v, rbh, soh, 4u * (unsigned)(((c0 + 2 * w) * 7 + sb - 1) * (int)dvol + iz * plane_cells));
+                if (NG == 1) {                                    // both channels in one instruction (lane / 32)
+                    const float v = tile[(2 * w + (lane >> 5)) * CHS + sb * CELLS + (lane & 31)];
+                    if (sb == 0) cl_store<false>(v, rb0, so0, 4u * ((unsigned)((c0 + 2 * w) * dvol) + zoff));
+                    else cl_store<false>(v, rbh, soh, 4u * ((unsigned)(((c0 + 2 * w) * 7 + sb - 1) * dvol) + zoff));
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int cb = c0 + 2 * w + h;
+                        if (cb >= a.C) continue;
+#pragma unroll
+                        for (int part = 0; part < NG / 2; ++part) {                   // 64 cells = 256 contiguous bytes each
+                            const float v = tile[(2 * w + h) * CHS + sb * CELLS + part * 64 + lane];
+                            const unsigned lo = (f0 + part * 64 + lane < plane_cells) ? so0 + 256u * part : kOutside;
+                            if (sb == 0) cl_store<false>(v, rb0, lo, 4u * ((unsigned)(cb * dvol) + zoff));
+                            else cl_store<false>(v, rbh, lo, 4u * ((unsigned)((cb * 7 + sb - 1) * dvol) + zoff));
+                        }
+                    }
+                }
             }
             buf ^= 1;
         }
@@ -449,7 +477,7 @@ extern "C" int lfgc_idwt_level_cl_f32(const float* lll, const float* hf, const f
     a.zchunk = pick_zchunk(ptiles * a.ngroups, d0 + 1, cw == 32 ? 1 : cw == 16 ? 2 : 4);    // 96 VGPRs: 4 waves per SIMD
     a.nchunks = (d0 + 1 + a.zchunk - 1) / a.zchunk;
     hipStream_t st = (hipStream_t)stream;
-    bool nt = (long long)t0 * t1 * t2 * channel_stride * 4 > (48LL << 20);             // see cl_store
+    bool nt = cw == 32 && (long long)t0 * t1 * t2 * channel_stride * 4 > (48LL << 20); // see cl_store
     if (const char* e = getenv("LFGC_CL_NT")) nt = e[0] == '1';                         // diagnostics
     if (cw == 32) {
         static bool raised[LFGC_MAX_DEVICES] = {false};     // 67.6 KB of LDS: above the 64 KB default limit
@@ -477,14 +505,29 @@ extern "C" int lfgc_idwt_level_cl_bwd_f32(const float* d_out_cl, const float* ta
     a.lo0 = (2 * d0 + 2 - t0) / 2; a.lo1 = (2 * d1 + 2 - t1) / 2; a.lo2 = (2 * d2 + 2 - t2) / 2;
     a.d0 = d0; a.d1 = d1; a.d2 = d2;
     for (int i = 0; i < 8; ++i) a.taps[i] = taps[i];
-    const long long ptiles = ((long long)d1 * d2 + kCells - 1) / kCells;
     const int cw = channel_stride % 16 == 0 ? 16 : 8;
+    // cells per workgroup: 64 on a large plane (256-byte runs per (channel, band): one whole line + two shared ones per
+    // store instead of two shared ones: 188 -> 176 us at d = 65; 128 cells: no further gain), 32 on a small one (d = 33:
+    // 23.6 vs 24.2 us, more workgroups)
+    int ng = (long long)d1 * d2 >= 3072 ? 2 : 1;
+    if (const char* e = getenv("LFGC_CL_ADJ_NG")) { const int v = atoi(e); if (v == 1 || v == 2) ng = v; }   // diagnostics
+    const long long ptiles = ((long long)d1 * d2 + kCells * ng - 1) / (kCells * ng);
     a.ngroups = channel_stride / cw;
     if (ptiles * a.ngroups > 0x0fffffffLL) return LFGC_E_UNSUPPORTED;
     a.ptiles = (int)ptiles;
-    a.zchunk = pick_zchunk(ptiles * a.ngroups, d0, cw == 16 ? 3 : 6);      // 76 VGPRs: 6 waves per SIMD
+    a.zchunk = pick_zchunk(ptiles * a.ngroups, d0, (cw == 16 ? (ng == 2 ? 2 : 3) : (ng == 2 ? 4 : 6)));   // LDS 33 KB x ng per 16 channels; <= 6 waves per SIMD
     a.nchunks = (d0 + a.zchunk - 1) / a.zchunk;
     hipStream_t st = (hipStream_t)stream;
-    if (cw == 16) return launch_cl(analysis_cl_kernel<16>, 512, a, 2 * 16 * ClShape<16>::CHS * 4, st);
-    return launch_cl(analysis_cl_kernel<8>, 256, a, 2 * 8 * ClShape<8>::CHS * 4, st);
+    const int lds = 2 * cw * (8 * kCells * ng + 1) * 4;
+    if (ng == 2 && cw == 16) {
+        static bool raised[LFGC_MAX_DEVICES] = {false};     // 65.7 KB of LDS: above the 64 KB default limit
+        const int dev = lfgc_current_device();
+        if (!raised[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(analysis_cl_kernel<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+            raised[dev] = true;
+        }
+    }
+    if (ng == 2) return cw == 16 ? launch_cl(analysis_cl_kernel<16, 2>, 512, a, lds, st) : launch_cl(analysis_cl_kernel<8, 2>, 256, a, lds, st);
+    return cw == 16 ? launch_cl(analysis_cl_kernel<16, 1>, 512, a, lds, st) : launch_cl(analysis_cl_kernel<8, 1>, 256, a, lds, st);
 }

@@ -157,6 +157,9 @@ CL_CASES = [   # (C, d, t): channel counts around every stride, ragged planes, e
     (30, (8, 9, 40), (17, 18, 81)), (32, (17, 18, 16), (33, 34, 31)), (32, (33, 33, 33), (64, 64, 64)),
     (3, (1, 1, 1), (2, 3, 4)), (32, (2, 70, 3), (5, 140, 6)),
     (40, (5, 6, 7), (11, 13, 15)),      # C > 32: the wrappers fall back to level + layout conversion
+    # large planes: 16-wave synthesis workgroups (32 channels), 64-cell adjoint tiles (16- and 8-channel groups)
+    (32, (2, 64, 64), (5, 129, 128)), (16, (2, 64, 64), (4, 128, 128)), (8, (3, 60, 60), (6, 119, 120)),
+    (32, (65, 65, 65), (128, 128, 128)),   # cfg-5 last level: streaming stores (grid > 48 MiB)
 ]
 
 
