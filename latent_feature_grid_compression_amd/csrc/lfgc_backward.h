@@ -485,8 +485,11 @@ struct LfgcWgradArgs {
     long long n;
     long long ntiles;          // 32-sample tiles that hold data (multiple of 4: whole workgroup batches)
     int L;
-    float* slabs;              // [gridDim.x][slab_floats]
+    float* slabs;              // [gridDim.x / roles][slab_floats]
     int slab_floats;
+    int roles;                 // 1: a workgroup computes every layer's gradient for its tiles (one slab per workgroup);
+                               // L: workgroup b computes layer b % L only (the last role also the head) for the tiles of
+                               // group b / L -- a quarter of the slabs for the same operand reads
     const float* dscale;       // [tiles][L] from the data kernel, or nullptr: exact f32 MFMA contraction
 };
 
@@ -521,7 +524,7 @@ __device__ __forceinline__ void lfgc_load16(const float* __restrict__ base, int 
 template <int MT, int NT, bool LAYER0, int KS0>
 __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, float* __restrict__ slab_l, int ncol,
                                                  int k0p, long long per_tile, long long dper_tile,
-                                                 int lane, int wave8, float* s_comb) {
+                                                 int lane, int wave8, float* s_comb, int grp, int ngrp) {
     const int half = wave8 >> 2, wave = wave8 & 3;
     constexpr int WPN = 4 / NT;                       // waves sharing one column tile
     constexpr int TPW = (MT + WPN - 1) / WPN;         // row tiles per wave
@@ -551,7 +554,7 @@ __device__ __forceinline__ void lfgc_wgrad_layer(const LfgcWgradArgs& a, int l, 
     const int ra = (i & 3) + 4 * (i >> 3), ha = (i >> 2) & 1;
     const long long aoff_base = (long long)l * (64 * 16 * MT) + (long long)ra * 64 + ha * 32;
 
-    for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
+    for (long long t = grp + (long long)half * ngrp; t < a.ntiles; t += 2LL * ngrp) {
         float Bv[16];
         lfgc_load16(a.stash + t * per_tile + boff, kk, Bv);
         if (LAYER0) {
@@ -672,16 +675,19 @@ __global__ __launch_bounds__(512, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
     const int L = a.L;
     const long long per_tile = 64LL * (KS0 + L * 16 * MT);
     const long long dper_tile = 64LL * (L * 16 * MT);
-    float* slab = a.slabs + (long long)blockIdx.x * a.slab_floats;
+    const int R = a.roles;
+    const int role = (int)blockIdx.x % R, grp = (int)blockIdx.x / R, ngrp = (int)gridDim.x / R;    // workgroup-uniform
+    float* slab = a.slabs + (long long)grp * a.slab_floats;
 
-    lfgc_wgrad_layer<MT, NT0, true, KS0>(a, 0, slab, K0R, K0P, per_tile, dper_tile, lane, wave, s_comb);
+    if (R == 1 || role == 0) lfgc_wgrad_layer<MT, NT0, true, KS0>(a, 0, slab, K0R, K0P, per_tile, dper_tile, lane, wave, s_comb, grp, ngrp);
     for (int l = 1; l < L; ++l) {
+        if (R != 1 && role != l) continue;
         float* slab_l = slab + (HP * K0R + HP) + (long long)(l - 1) * (HP * HP + HP);
-        lfgc_wgrad_layer<MT, MT, false, KS0>(a, l, slab_l, HP, K0P, per_tile, dper_tile, lane, wave, s_comb);
+        lfgc_wgrad_layer<MT, MT, false, KS0>(a, l, slab_l, HP, K0P, per_tile, dper_tile, lane, wave, s_comb, grp, ngrp);
     }
 
     // final Linear: dWf[k] = sum_n dy_n H_L[n,k], dbf = sum_n dy_n.  Wave w owns column tile w.
-    {
+    if (R == 1 || role == L - 1) {
         float* slab_f = slab + (HP * K0R + HP) + (long long)(L - 1) * (HP * HP + HP);
         const int i = lane & 31, kk = lane >> 5;
         const int half = wave >> 2, w4 = wave & 3;
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void lfgc_bwd_weight_kernel(const LfgcWgrad
         if (w4 < MT) {
             const int r = (i & 3) + 4 * (i >> 3), hb = (i >> 2) & 1;
             const long long boff = 64LL * KS0 + (long long)(L - 1) * (64 * 16 * MT) + (long long)(w4 * 16 + r) * 64 + hb * 32;
-            for (long long t = blockIdx.x + (long long)half * gridDim.x; t < a.ntiles; t += 2LL * gridDim.x) {
+            for (long long t = grp + (long long)half * ngrp; t < a.ntiles; t += 2LL * ngrp) {
                 float Bv[16];
                 lfgc_load16(a.stash + t * per_tile + boff, kk, Bv);
                 bool bad = false;

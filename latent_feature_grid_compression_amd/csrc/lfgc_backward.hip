@@ -21,7 +21,8 @@ const int kMaxSlabs = LFGC_MAX_SLABS;   // workgroups of the weight-gradient ker
 
 struct Carve {
     long long ntiles, nbatches;
-    int nslabs;
+    int nslabs;                // partial slabs = tile groups of the weight-gradient kernel
+    int roles;                 // workgroups per tile group (LfgcWgradArgs::roles)
     long long dstash_floats, slab_floats_total, dscale_floats, dfeat_floats;
 };
 
@@ -31,6 +32,13 @@ Carve carve(const LfgcPlan& p, long long n) {
     c.ntiles = c.nbatches * 8;
     c.nslabs = (int)(c.ntiles < kMaxSlabs ? c.ntiles : kMaxSlabs);
     if (c.nslabs < 1) c.nslabs = 1;
+    // enough tiles: one workgroup per (tile group, layer) instead of per tile group -- the same kMaxSlabs workgroups read
+    // the same operands but leave L times fewer slabs (cfg-3 step: 69 -> 17 MB written, and read again by the reduction)
+    c.roles = 1;
+    if (c.ntiles >= 2LL * kMaxSlabs && p.L > 1 && !getenv("LFGC_WGRAD_NO_SPLIT")) {
+        c.roles = p.L;
+        c.nslabs = kMaxSlabs / p.L;
+    }
     c.dstash_floats = c.ntiles * 64LL * (p.L * 16 * p.MT);
     c.slab_floats_total = (long long)c.nslabs * lfgc_slab_floats(p);
     c.dscale_floats = (c.ntiles * p.L + 3) / 4 * 4;     // one power-of-two scale per (tile, layer), f16 builds
@@ -95,7 +103,7 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
 
     LfgcWgradArgs w;
     w.stash = stash; w.dstash = dstash; w.d_out = d_out; w.n = n; w.ntiles = c.ntiles; w.L = p.L;
-    w.slabs = slabs; w.slab_floats = lfgc_slab_floats(p);
+    w.slabs = slabs; w.slab_floats = lfgc_slab_floats(p); w.roles = c.roles;
     w.dscale = precision == LFGC_PRECISION_F32 ? nullptr : dscale;     // f16 builds: f16-split contraction (lfgc_backward.h)
 
     const int cus = lfgc_num_cus();       // per device
@@ -120,10 +128,10 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
 
     int rc;
     switch (p.CH) {
-        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
-        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs, st); break;
+        case 8: rc = lfgc_bwd_dispatch_ch8(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs * c.roles, st); break;
+        case 16: rc = lfgc_bwd_dispatch_ch16(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs * c.roles, st); break;
+        case 24: rc = lfgc_bwd_dispatch_ch24(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs * c.roles, st); break;
+        case 32: rc = lfgc_bwd_dispatch_ch32(p.MT, a, w, waves, precision, lds_bytes, (int)grid_data, c.nslabs * c.roles, st); break;
         default: return LFGC_E_UNSUPPORTED;
     }
     if (rc != LFGC_OK) return rc;
