@@ -418,6 +418,7 @@ __global__ __launch_bounds__(32 * CW) void analysis_cl_kernel(const AnalysisClAr
 // z chunk length: few enough workgroups per slot that no round is mostly idle, long enough that the warm-up plane of a
 // chunk (read and contracted, nothing emitted) stays a small share.
 int pick_zchunk(long long columns, int nz, int slots_per_cu) {
+    if (const char* e = getenv("LFGC_CL_NCHUNKS")) { const int nc = atoi(e); if (nc >= 1 && nc <= nz) return (nz + nc - 1) / nc; }   // diagnostics
     const int slots = slots_per_cu * lfgc_num_cus();
     long long best_cost = -1;
     int best = nz;
