@@ -53,15 +53,20 @@ else:
     buf = torch.zeros(nslots * 20, dtype=torch.int64, device=dev)
     lib.lfgc_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
     lib.lfgc_debug_set_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    train = len(sys.argv) > 3 and sys.argv[3] == 'train'      # `run headline train`: the cfg-3 train-step batch, stash written
     with torch.no_grad():
         grid, packed = model._decoded_channel_last(), model._packed()
         res = (w['vol'],) * 3
         for _ in range(3):
-            y, _ = ops.forward_raw(model._descriptor(), grid, packed, lattice=(res, 0, w['vol'], 32), clamp=True)
+            if train:
+                pos = torch.rand(32768, 3, device=dev) * 2 - 1
+                y, _ = ops.forward_raw(model._descriptor(), grid, packed, pos=pos, clamp=False, want_stash=True)
+            else:
+                y, _ = ops.forward_raw(model._descriptor(), grid, packed, lattice=(res, 0, w['vol'], 32), clamp=True)
         torch.cuda.synchronize()
     s = buf.cpu().numpy().reshape(nslots, 20).astype(np.float64)
     s = s[s[:, 16] > 0]
-    ntiles = w['vol'] ** 3 / 32 / len(s)
+    ntiles = (32768 if train else w['vol'] ** 3) / 32 / len(s)
     names = {0: 'loop/tail+store', 1: 'wait for own weight-DMA pieces', 2: 'inputs issue (positions, corner loads)',
              3: 'barrier before layer 0', 4: 'layer 0 (+ embed, interpolate, split)', 5: 'barrier before layer 1', 6: 'layer 1',
              7: 'barrier before layer 2', 8: 'layer 2', 9: 'barrier before layer 3', 10: 'layer 3', 11: 'barrier before layer 4',
