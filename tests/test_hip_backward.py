@@ -201,32 +201,16 @@ def test_device_lattice_sampler_matches_index_dataset(dev):
     assert torch.equal(raw_k.cpu(), raw_t) and torch.equal(norm_k.cpu(), norm_t)
 
 
-def _philox4x32_10(c, k):
-    """numpy restatement of Philox4x32-10 (Salmon et al., SC'11; the generator include/lfgc.h names for
-    lfgc_lattice_sample_f32): c (n,4) uint32 counters, k (2,) uint32 key -> (n,4) uint32."""
-    c = c.astype(np.uint64).copy()
-    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
-    m32 = np.uint64(0xFFFFFFFF)
-    for _ in range(10):
-        p0 = np.uint64(0xD2511F53) * c[:, 0]
-        p1 = np.uint64(0xCD9E8D57) * c[:, 2]
-        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & m32
-        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & m32
-        c = np.stack([n0, p1 & m32, n2, p0 & m32], 1)
-        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
-        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
-    return c.astype(np.uint32)
+from philox_ref import philox4x32_10 as _philox4x32_10      # numpy restatement, pinned by known-answer vectors on the CPU
 
 
 def test_fused_lattice_sampler(dev):
     """Row f2, one-kernel form: the indices the kernel draws are the documented Philox stream (checked against the numpy
-    restatement above, incl. the published known-answer vector), the positions are IndexDataset's for those indices, the
-    draw counter advances on the device -- also across replays of a captured launch."""
+    restatement in tests/philox_ref.py, itself pinned by the published known-answer vectors in test_host_logic.py), the
+    positions are IndexDataset's for those indices, the draw counter advances on the device -- also across replays of a
+    captured launch."""
     from latent_feature_grid_compression_amd import ops
     from latent_feature_grid_compression_amd.data.IndexDataset import DeviceLatticeSampler, IndexDataset
-    # known-answer test of the restatement (Random123 kat_vectors: philox4x32-10, all-ones counter and key)
-    kat = _philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), np.array([0xFFFFFFFF, 0xFFFFFFFF], np.uint32))[0]
-    assert [int(v) for v in kat] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     shape = (255, 255, 255)
     ds = IndexDataset(shape, 16, build_index_table=False)
     nvox = 255 ** 3

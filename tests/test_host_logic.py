@@ -81,6 +81,17 @@ def test_pure_host_entry_points(built_lib):
     assert lib.lfgc_lattice_sample_f32(0, None, 1, None, None, None, None, None, None, None, None) == -1
 
 
+def test_philox_restatement_matches_published_vectors():
+    """Random123's kat_vectors for philox4x32-10: the checker of test_fused_lattice_sampler is itself pinned."""
+    from philox_ref import philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(np.array([ctr], np.uint32), np.array(key, np.uint32))[0]
+        assert tuple(int(v) for v in got) == want
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from latent_feature_grid_compression_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)
