@@ -302,7 +302,9 @@ int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions,
 
 /* Backward of lfgc_forward_f32 (what autograd derives for model/Feature_Grid_Model.py:62-75;
  * triggered at training/training.py:137).  positions->pos must be non-NULL.
- *   precision   LFGC_PRECISION_* for the data-gradient chain dH_{l-1} = W_l^T dA_l (weight gradients: exact fp32)
+ *   precision   LFGC_PRECISION_* of the data-gradient chain dH_{l-1} = W_l^T dA_l and of the weight-gradient contraction
+ *               dW_l = dA_l^T H_{l-1} (f16 builds: f16-split / single f16 products with fp32 accumulation; a tile whose
+ *               inputs leave the f16 range takes the exact chain)
  *   stash       device, written by the forward call with the same inputs
  *   d_out       device (N)
  *   d_grid_cl   device (D,H,W,Cs)  ACCUMULATED into with float atomics (caller zeroes it)
@@ -316,6 +318,19 @@ int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions
                       const float* packed, int precision, const float* stash, const float* d_out,
                       float* d_grid_cl, float* const* d_weights, float* const* d_biases, float* d_pos,
                       void* workspace, int64_t workspace_bytes, lfgc_stream_t stream);
+
+/* The reduced-precision pair under the names SURVEY section 8(b) gives it (BASELINE config 3, "bf16 train step"; the
+ * reference itself has no reduced-precision path): exactly lfgc_forward_f32 / lfgc_backward_f32 with precision =
+ * LFGC_PRECISION_F16 -- layer GEMMs as single 16-bit products on the matrix pipe, fp32 accumulation, fp32 inputs, outputs
+ * and master parameters.  The 16-bit format is IEEE f16, not bfloat16: the same MFMA rate on gfx950, 3 more mantissa bits,
+ * and every range on this path is known (weights pre-scaled per layer, activations < 65504, gradients rescaled per tile).
+ * No status word: out-of-range samples come out as NaN. */
+int lfgc_forward_bf16(const lfgc_mlp_desc* desc, const lfgc_positions* positions, const float* grid_cl, int D, int H, int W,
+                      const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream);
+int lfgc_backward_bf16(const lfgc_mlp_desc* desc, const lfgc_positions* positions, const float* grid_cl, int D, int H, int W,
+                       const float* packed, const float* stash, const float* d_out, float* d_grid_cl,
+                       float* const* d_weights, float* const* d_biases, float* d_pos,
+                       void* workspace, int64_t workspace_bytes, lfgc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ground-truth sampler and volume statistics

@@ -74,6 +74,11 @@ SIGNATURES = {
     'lfgc_backward_f32': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p, _PP, _PP, c_void_p,
                                   c_void_p, c_int64, c_void_p]),
+    'lfgc_forward_bf16': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
+                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    'lfgc_backward_bf16': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, _PP, _PP, c_void_p,
+                                   c_void_p, c_int64, c_void_p]),
     'lfgc_gt_interp_f32': (c_int, [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float),
                                    c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'lfgc_gt_mse_workspace_bytes': (c_int64, [c_int64]),

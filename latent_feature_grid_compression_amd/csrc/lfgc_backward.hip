@@ -151,3 +151,11 @@ extern "C" int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions
     LFGC_HIP_CHECK_LAUNCH();
     return LFGC_OK;
 }
+
+extern "C" int lfgc_backward_bf16(const lfgc_mlp_desc* desc, const lfgc_positions* positions, const float* grid_cl, int D, int H,
+                                  int W, const float* packed, const float* stash, const float* d_out, float* d_grid_cl,
+                                  float* const* d_weights, float* const* d_biases, float* d_pos,
+                                  void* workspace, int64_t workspace_bytes, lfgc_stream_t stream) {
+    return lfgc_backward_f32(desc, positions, grid_cl, D, H, W, packed, LFGC_PRECISION_F16, stash, d_out, d_grid_cl, d_weights,
+                             d_biases, d_pos, workspace, workspace_bytes, stream);
+}

@@ -142,3 +142,8 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
         default: return LFGC_E_UNSUPPORTED;
     }
 }
+
+extern "C" int lfgc_forward_bf16(const lfgc_mlp_desc* desc, const lfgc_positions* positions, const float* grid_cl, int D, int H,
+                                 int W, const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream) {
+    return lfgc_forward_f32(desc, positions, grid_cl, D, H, W, packed, LFGC_PRECISION_F16, clamp, out, stash, nullptr, stream);
+}

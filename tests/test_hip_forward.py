@@ -211,6 +211,42 @@ def test_last_level_channel_last_against_oracle(dev):
     assert rel_err(d_hf.cpu().numpy(), data.grad[0, :, 1:].numpy()) < 2e-6
 
 
+def test_reduced_precision_entry_points_are_the_f16_mode(dev):
+    """lfgc_forward_bf16 / lfgc_backward_bf16 (the names SURVEY 8(b) lists) = the f32 entries with LFGC_PRECISION_F16."""
+    from latent_feature_grid_compression_amd import ops, _lib
+    g = np.load(os.path.join(GOLD, 'fwd_c6g17h32l4.npz'))
+    m = build_from_golden(g, dev).train()
+    lib = _lib.load()
+    desc = m._descriptor()
+    grid = m._decoded_channel_last().detach()
+    packed = m._packed()
+    pos = torch.from_numpy(np.random.default_rng(2).uniform(-1, 1, (777, 3)).astype(np.float32)).to(dev)
+    want, stash_w = ops.forward_raw(desc, grid, packed, pos=pos, want_stash=True, precision='f16', range_fallback=False)
+    ps, n = ops._positions_struct(pos)
+    D, H, W, _ = grid.shape
+    out = torch.empty(n, device=dev)
+    stash = torch.empty_like(stash_w)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.lfgc_forward_bf16(ctypes.byref(desc), ctypes.byref(ps), grid.data_ptr(), D, H, W, packed.data_ptr(), 0,
+                                 out.data_ptr(), stash.data_ptr(), st) == 0
+    assert torch.equal(out, want) and torch.equal(stash, stash_w)
+    weights, biases = m._mlp_params()
+    d_y = torch.from_numpy(np.random.default_rng(3).standard_normal(n).astype(np.float32)).to(dev)
+    w_grid, w_w, w_b, _ = ops.backward_raw(desc, grid, packed, pos, stash_w, d_y, weights, biases, False, precision='f16')
+    d_grid = torch.zeros_like(grid)
+    d_w = [torch.empty_like(w) for w in weights]
+    d_b = [torch.empty_like(b) for b in biases]
+    nbytes = int(lib.lfgc_backward_workspace_bytes(ctypes.byref(desc), n))
+    ws = torch.empty(max(nbytes, 16) // 4, device=dev)
+    wp, _k1 = _lib.ptr_array([t.data_ptr() for t in d_w])
+    bp, _k2 = _lib.ptr_array([t.data_ptr() for t in d_b])
+    assert lib.lfgc_backward_bf16(ctypes.byref(desc), ctypes.byref(ps), grid.data_ptr(), D, H, W, packed.data_ptr(),
+                                  stash_w.data_ptr(), d_y.data_ptr(), d_grid.data_ptr(), wp, bp, None, ws.data_ptr(), nbytes, st) == 0
+    for a_, b_ in zip(d_w + d_b, list(w_w) + list(w_b)):
+        assert torch.equal(a_, b_)                               # weight gradients: deterministic slab reduction
+    assert float((d_grid - w_grid).abs().max()) <= 1e-5 * float(w_grid.abs().max())     # float atomics: order-dependent last bits
+
+
 def test_dense_stencil_for_non_separable_filter(dev):
     """A filter buffer that is NOT an outer product of a 1-D bank (never produced by the reference, but a legal buffer
     value) takes the dense 4^3-tap kernels: forward, adjoint and the analysis form, against the oracle's convolutions."""
