@@ -48,7 +48,7 @@ def traffic_bytes(workload, precision):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs for
     FETCH_SIZE and WRITE_SIZE; bytes = 2 x FETCH_SIZE KB (gfx950 correction for 16-B/lane reads) + WRITE_SIZE KB), or
     None when no profile of this (workload, build) is committed.  Newest round first."""
-    for rnd in ('r2', 'r1'):
+    for rnd in ('r3', 'r2', 'r1'):
         path = os.path.join(ROOT, 'profiles', rnd, 'bench_headline_pmc.json')
         try:
             with open(path) as fh:
@@ -65,6 +65,8 @@ WORKLOADS = {
                      desc='256^3 full-volume reconstruction, 64^3x32ch grid (4-level db2), MLP 4x128, fp32'),
     'cfg5': dict(vol=1024, C=32, G=128, H=128, L=4, levels=3,
                  desc='1024^3 full-volume reconstruction, 128^3x32ch grid (3-level db2), MLP 4x128, fp32'),
+    'cfg5_l5': dict(vol=1024, C=32, G=128, H=128, L=4, levels=5,
+                    desc='1024^3 full-volume reconstruction, 128^3x32ch grid (5-level db2 = the reference default), MLP 4x128, fp32'),
     'cfg2': dict(vol=150, C=16, G=32, H=64, L=4,
                  desc='150^3 full-volume reconstruction, 32^3x16ch grid (3-level db2), MLP 4x64, fp32'),
 }
@@ -164,8 +166,28 @@ def _event_ms(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-def forward_extra(name, device, precision='f16x2', reps=3):
-    """One more BASELINE shape under the same clock: full-volume fused forward of workload `name` (+ its decode)."""
+def oracle_parts(model):
+    """Host copies of everything the oracle's functional restatement takes."""
+    layers = list(model.net_layers) + [model.final_layer]
+    return ([p.detach().cpu() for p in model.feature_grid], [l.weight.detach().cpu() for l in layers],
+            [l.bias.detach().cpu() for l in layers], model.filter.filter_rev.detach().cpu())
+
+
+def parity_stats(mine, ref):
+    """north_star's figures for one block of outputs: max|y - y_ref| / max|y_ref| and the PSNR of y against y_ref."""
+    mine, ref = mine.double().reshape(-1), ref.double().reshape(-1)
+    mse = float(((mine - ref) ** 2).mean())
+    rng_ = float(ref.max() - ref.min())
+    return {'max_rel_err_vs_oracle': float((mine - ref).abs().max() / ref.abs().max()), 'tolerance': 1e-5,
+            'psnr_of_hip_vs_oracle_dB': (10.0 * math.log10(rng_ ** 2 / mse)) if mse > 0 else float('inf'),
+            'samples': int(ref.numel())}
+
+
+def forward_extra(name, device, precision='f16x2', reps=3, check_tiles=0, random_batch=0):
+    """One more BASELINE shape under the same clock: full-volume fused forward of workload `name` (+ its decode).
+    check_tiles > 0: in-run parity + PSNR of that many 32^3 tiles of the 256^3 sub-block at the origin against the oracle
+    (cfg 5).  random_batch > 0: also a uniform-random U(-1,1)^3 batch of that many samples through the
+    position-list entry (cfg 2), timed and checked against the oracle on its first 65 536 samples."""
     from latent_feature_grid_compression_amd import ops
     w = WORKLOADS[name]
     model = build_model(w, seed=2003, device=device)
@@ -189,32 +211,86 @@ def forward_extra(name, device, precision='f16x2', reps=3):
     bps = 12 + 4 + 8 * w['C'] * 4
     K0 = 3 + 12 + w['C']
     fl = 2 * (K0 * w['H'] + (w['L'] - 1) * w['H'] ** 2 + w['H'])
+    r = {'workload': w['desc'], 'precision': precision, 'samples': n, 'kernel_ms': k_ms, 'decode_ms': d_ms,
+         'wavelet_levels': len(model.feature_grid) - 1,
+         'value': n / (k_ms * 1e-3) / 1e6, 'unit': 'Msamples/s (forward launch only; decode_ms beside it)',
+         'algorithmic_TFLOPs': fl * n / (k_ms * 1e-3) / 1e12,
+         'hbm_algorithmic': {'bytes_per_sample': bps, 'achieved_GBs': bps * n / (k_ms * 1e-3) / 1e9,
+                             'frac': bps * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if check_tiles or random_batch:
+        from oracle import ref_torch as R
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        coeffs, weights, biases, frev = oracle_parts(model)
+        with torch.no_grad():
+            dense = R.decode_volume(coeffs, model.shape_array, frev)
+            if check_tiles:
+                ds = R.VolumeIndexing(res)
+                sub = min(256, w['vol'])
+                tiles = [b for b in R.tile_iter(ds.vol_res_touple, 32) if b[1] <= sub and b[3] <= sub and b[5] <= sub]
+                step = max(1, len(tiles) // check_tiles)
+                vol = out.view(res)
+                mine, ref = [], []
+                for b in tiles[::step][:check_tiles]:
+                    ref.append(R.forward_from_grid(dense, weights, biases, R.tile_positions(ds, b).reshape(-1, 3), 2).clamp(-1, 1).reshape(-1))
+                    mine.append(vol[b[0]:b[1], b[2]:b[3], b[4]:b[5]].reshape(-1).cpu())
+                r['parity_256_subblock'] = dict(parity_stats(torch.cat(mine), torch.cat(ref)), tiles=len(ref),
+                                                block='32^3 tiles spread over the 256^3 sub-block at the origin')
+            if random_batch:
+                rng = np.random.Generator(np.random.PCG64(3002))
+                pos = torch.from_numpy(rng.uniform(-1, 1, (random_batch, 3)).astype(np.float32)).to(device)
+                yb = torch.empty(random_batch, dtype=torch.float32, device=device)
+                fb = lambda: ops.forward_raw(model._descriptor(), grid, packed, pos=pos, clamp=False, out=yb, precision=precision)
+                fb()
+                torch.cuda.synchronize()
+                b_ms = _event_ms(fb, reps)
+                nchk = min(65536, random_batch)
+                yr = R.forward_from_grid(dense, weights, biases, pos[:nchk].cpu(), 2).reshape(-1)
+                r['random_batch'] = dict(parity_stats(yb[:nchk].cpu(), yr), batch=random_batch, kernel_ms=b_ms,
+                                         value=random_batch / (b_ms * 1e-3) / 1e6, unit='Msamples/s',
+                                         positions='U(-1,1)^3, numpy PCG64(3002); parity on the first %d samples' % nchk)
+                del pos, yb
     del out, grid, model
     torch.cuda.empty_cache()
-    return {'workload': w['desc'], 'precision': precision, 'samples': n, 'kernel_ms': k_ms, 'decode_ms': d_ms,
-            'value': n / (k_ms * 1e-3) / 1e6, 'unit': 'Msamples/s (forward launch only; decode_ms beside it)',
-            'algorithmic_TFLOPs': fl * n / (k_ms * 1e-3) / 1e12,
-            'hbm_algorithmic': {'bytes_per_sample': bps, 'achieved_GBs': bps * n / (k_ms * 1e-3) / 1e9,
-                                'frac': bps * n / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    return r
 
 
-def train_step_extra(device, precision='f16x2', steps=100, warmup=10):
-    """BASELINE config 3 train step (training/training.py:95-138): 32 768 lattice samples of a 255^3 volume -> forward ->
-    ground truth + MSE -> backward -> Adam(lr 0.008, torch fused), the whole step captured in one HIP graph and replayed."""
+def smooth_volume(shape, seed, device):
+    """SURVEY 8(d), cfg 3: a smooth synthetic volume -- 8 random low-frequency sinusoids + 0.05 x uniform noise, min-max
+    normalised to [-1, 1] like data/IndexDataset.py:15-17 -- so that loss and PSNR of a train run mean something."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ax = [torch.linspace(0.0, 1.0, n, device=device, dtype=torch.float32) for n in shape]
+    X, Y, Z = torch.meshgrid(*ax, indexing='ij')
+    vol = torch.zeros(shape, dtype=torch.float32, device=device)
+    for _ in range(8):
+        f = rng.uniform(0.5, 3.0, 3) * rng.choice([-1.0, 1.0], 3)
+        ph, amp = rng.uniform(0, 2 * math.pi), rng.uniform(0.5, 1.0)
+        vol += float(amp) * torch.sin(2 * math.pi * (float(f[0]) * X + float(f[1]) * Y + float(f[2]) * Z) + float(ph))
+    vol += 0.05 * (torch.from_numpy(rng.random(shape, dtype=np.float32)).to(device) * 2 - 1)
+    lo, hi = vol.min(), vol.max()
+    return (vol - lo) / (hi - lo) * 2 - 1
+
+
+def cfg3_train_setup(device, precision='f16x2', seed=2003, volume='smooth', n=2048 * 16, vol_shape=(255, 255, 255), workload=None):
+    """The BASELINE config-3 train step (training/training.py:95-138) as bench.py times it and tests/ replays it: model,
+    volume, on-device lattice sampler (Philox stream `1003`, counter on the device), torch fused capturable Adam(lr 0.008)
+    and `step()` = draw -> forward -> fused ground truth + MSE -> backward -> Adam.  Every launch of `step` is
+    stream-ordered and allocation-free after the first call, so it can be captured in one HIP graph."""
     from latent_feature_grid_compression_amd.data.Interpolation import trilinear_mse_loss, mse_unit_grad
     from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
-    w = WORKLOADS['headline']
-    model = build_model(w, seed=2003, device=device).train()
+    w = workload or WORKLOADS['headline']
+    model = build_model(w, seed=seed, device=device).train()
     model.precision = precision
-    rng = np.random.Generator(np.random.PCG64(1003))
-    vol = torch.from_numpy(rng.uniform(-1, 1, (255, 255, 255)).astype(np.float32)).to(device)
-    ds = IndexDataset((255, 255, 255), 16, build_index_table=False)
+    if volume == 'smooth':
+        vol = smooth_volume(vol_shape, 1003, device)
+    else:
+        rng = np.random.Generator(np.random.PCG64(1003))
+        vol = torch.from_numpy(rng.uniform(-1, 1, vol_shape).astype(np.float32)).to(device)
+    ds = IndexDataset(vol_shape, 16, build_index_table=False)
     opt = torch.optim.Adam(model.parameters(), lr=0.008, capturable=True, fused=True)
-    n = 2048 * 16
     mn_h, mx_h, rs_h = ds.min_idx.tolist(), ds.max_idx.tolist(), ds.vol_res.tolist()
     ds.min_idx, ds.max_idx, ds.scales = ds.min_idx.to(device), ds.max_idx.to(device), ds.scales.to(device)
-
-    unit = mse_unit_grad(device)                       # created outside the capture
+    unit = mse_unit_grad(device)                       # created outside any capture
+    ctx = {'model': model, 'vol': vol, 'ds': ds, 'opt': opt, 'n': n, 'bounds': (mn_h, mx_h, rs_h), 'seed': 1003}
 
     def step():
         raw, norm = ds.sample_positions(n, device, seed=1003)      # draw + positions: one kernel, counter on the device
@@ -223,30 +299,57 @@ def train_step_extra(device, precision='f16x2', steps=100, warmup=10):
         loss = trilinear_mse_loss(model(norm).squeeze(-1), raw, vol, mn_h, mx_h, rs_h)
         loss.backward(unit)
         opt.step()
+        ctx['last_batch'] = (raw, norm)
         return loss
 
+    ctx['step'] = step
+    return ctx
+
+
+def capture_train_step(ctx, eager_warmup=3):
+    """`eager_warmup` eager steps on a side stream (allocator + Adam state warm), then ONE step captured in a HIP graph.
+    Returns (graph, loss tensor the replays overwrite, [losses of the eager steps])."""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    eager = []
     with torch.cuda.stream(side):
-        for _ in range(3):
-            step()
+        for _ in range(eager_warmup):
+            eager.append(ctx['step']().detach().clone())
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
-    opt.zero_grad(set_to_none=True)
+    ctx['opt'].zero_grad(set_to_none=True)
     with torch.cuda.graph(graph):
-        loss = step()
+        loss = ctx['step']()
+    return graph, loss, eager
+
+
+def train_step_extra(device, precision='f16x2', steps=100, warmup=10):
+    """BASELINE config 3 train step: 32 768 lattice samples of a smooth synthetic 255^3 volume -> forward -> ground truth +
+    MSE -> backward -> Adam(lr 0.008, torch fused), the whole step captured in one HIP graph and replayed.  Reports the
+    loss of the first step (untrained model) and of the last one, and the PSNR of the full reconstructed volume after the
+    run: the optimizer has to have learnt something for these to move."""
+    from latent_feature_grid_compression_amd.visualization import OutputToVTK as V
+    ctx = cfg3_train_setup(device, precision)
+    graph, loss, eager = capture_train_step(ctx)
     for _ in range(warmup):
         graph.replay()
     torch.cuda.synchronize()
     ms = _event_ms(graph.replay, steps)
-    final = float(loss.detach())
-    del graph, opt, model, vol
+    loss_first, loss_last = float(eager[0]), float(loss.detach())
+    model, vol, n = ctx['model'], ctx['vol'], ctx['n']
+    model.eval()
+    with torch.no_grad():
+        rec = V.field_from_net_fused(ctx['ds'], model)
+        psnr, l1, mse, rmse = V.calculate_deviation_statistics(rec, vol, verbose=False)
+    total = len(eager) + warmup + steps
+    del graph, ctx, model, vol, rec
     torch.cuda.empty_cache()
-    return {'workload': 'cfg3 train step: 64^3x32ch grid (4-level db2), MLP 4x128, 32768 lattice samples of 255^3, '
-                        'fwd + GT + MSE + bwd + fused Adam, one HIP graph', 'precision': precision, 'samples': n,
-            'ms_per_step': ms, 'value': n / (ms * 1e-3) / 1e6, 'unit': 'Msamples/s', 'steps': steps, 'final_loss': final}
-
-
+    return {'workload': 'cfg3 train step: 64^3x32ch grid (4-level db2), MLP 4x128, 32768 lattice samples of a smooth '
+                        'synthetic 255^3 volume (8 low-frequency sinusoids + 0.05 noise), fwd + GT + MSE + bwd + fused '
+                        'Adam, one HIP graph', 'precision': precision, 'samples': n,
+            'ms_per_step': ms, 'value': n / (ms * 1e-3) / 1e6, 'unit': 'Msamples/s', 'steps': steps,
+            'optimizer_steps_total': total, 'loss_first': loss_first, 'loss_last': loss_last,
+            'psnr_dB_after_run': float(psnr), 'rmse_after_run': float(rmse)}
 
 
 def main():
@@ -438,8 +541,9 @@ def main():
             del vol
             torch.cuda.empty_cache()
             extra = {}
-            for key, fn in (('cfg2_forward', lambda: forward_extra('cfg2', device, args.precision, reps=10)),
-                            ('cfg5_forward', lambda: forward_extra('cfg5', device, args.precision, reps=2)),
+            for key, fn in (('cfg2_forward', lambda: forward_extra('cfg2', device, args.precision, reps=10, random_batch=4 * 1024 * 1024)),
+                            ('cfg5_forward', lambda: forward_extra('cfg5', device, args.precision, reps=2, check_tiles=8)),
+                            ('cfg5_forward_5level', lambda: forward_extra('cfg5_l5', device, args.precision, reps=2, check_tiles=8)),
                             ('cfg3_train_step', lambda: train_step_extra(device, args.precision)),
                             ('cfg3_train_step_reduced_f16', lambda: train_step_extra(device, 'f16'))):
                 try:

@@ -228,7 +228,9 @@ typedef struct lfgc_mlp_desc {
     int32_t d_out;           /* must be 1 */
 } lfgc_mlp_desc;
 
-/* 1 if the compiled kernel set covers this shape (C <= 64, H <= 128, L <= 8, n_freqs <= 4, d_in 3, d_out 1). */
+/* 1 if the compiled kernel set covers this shape: 1 <= C <= 32, 1 <= H <= 128, 1 <= L <= 8, n_freqs == 2, d_in 3, d_out 1
+ * (every reference configuration and the NAS ranges of Multi_Objective_NAS.py:127-143); anything else is refused with
+ * LFGC_E_UNSUPPORTED by the entry points below. */
 int lfgc_mlp_supported(const lfgc_mlp_desc* desc);
 
 /* Channel stride (floats) the sampler expects for the channel-last dense grid: C rounded up to 8. */
@@ -322,11 +324,15 @@ int lfgc_backward_f32(const lfgc_mlp_desc* desc, const lfgc_positions* positions
 /* The reduced-precision pair under the names SURVEY section 8(b) gives it (BASELINE config 3, "bf16 train step"; the
  * reference itself has no reduced-precision path): exactly lfgc_forward_f32 / lfgc_backward_f32 with precision =
  * LFGC_PRECISION_F16 -- layer GEMMs as single 16-bit products on the matrix pipe, fp32 accumulation, fp32 inputs, outputs
- * and master parameters.  The 16-bit format is IEEE f16, not bfloat16: the same MFMA rate on gfx950, 3 more mantissa bits,
- * and every range on this path is known (weights pre-scaled per layer, activations < 65504, gradients rescaled per tile).
- * No status word: out-of-range samples come out as NaN. */
+ * and master parameters.  The 16-bit format is IEEE f16, not bfloat16: the same MFMA rate on gfx950, 3 more mantissa bits.
+ * What bfloat16 would have over it is fp32's exponent range; the forward entry therefore takes the same `status` word as
+ * lfgc_forward_f32: with status != NULL a pass in which any sample left the f16 range (|pre-activation| >~ 800,
+ * |grid feature| >= 65504) is redone on the exact-fp32 build, predicated on the word, in stream order -- `out` and
+ * `stash` are then finite and reference-equivalent wherever the reference's are, as a bfloat16 path's would be finite.
+ * With status == NULL such samples come out as NaN.  The backward needs no word: every tile of dA is rescaled by a power
+ * of two before its conversion, and a weight-gradient tile whose activations leave the f16 range takes the exact MFMA. */
 int lfgc_forward_bf16(const lfgc_mlp_desc* desc, const lfgc_positions* positions, const float* grid_cl, int D, int H, int W,
-                      const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream);
+                      const float* packed, int clamp, float* out, float* stash, int32_t* status, lfgc_stream_t stream);
 int lfgc_backward_bf16(const lfgc_mlp_desc* desc, const lfgc_positions* positions, const float* grid_cl, int D, int H, int W,
                        const float* packed, const float* stash, const float* d_out, float* d_grid_cl,
                        float* const* d_weights, float* const* d_biases, float* d_pos,

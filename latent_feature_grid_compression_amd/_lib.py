@@ -75,7 +75,7 @@ SIGNATURES = {
                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p, _PP, _PP, c_void_p,
                                   c_void_p, c_int64, c_void_p]),
     'lfgc_forward_bf16': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
-                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'lfgc_backward_bf16': (c_int, [POINTER(MlpDesc), POINTER(Positions), c_void_p, c_int, c_int, c_int,
                                    c_void_p, c_void_p, c_void_p, c_void_p, _PP, _PP, c_void_p,
                                    c_void_p, c_int64, c_void_p]),

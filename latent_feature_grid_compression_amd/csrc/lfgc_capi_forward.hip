@@ -1,4 +1,5 @@
 // lfgc_capi_forward.hip -- C-ABI entry for the fused forward: argument checks, plan, dispatch.
+#include <stdlib.h>
 #include "lfgc_forward.h"
 
 int lfgc_fwd_dispatch_ch8(int MT, const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream);
@@ -92,6 +93,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     }
     // streamed nets: 8-wave workgroups once every CU gets at least one 256-sample batch, else 4-wave ones
     a.waves = (!a.resident && (n + 255) / 256 >= num_cus()) ? 8 : 4;
+    if (const char* e = getenv("LFGC_FWD_WAVES")) { if (!a.resident && (e[0] == '4' || e[0] == '8')) a.waves = e[0] - '0'; }   // diagnostics
     // always whole 256-sample groups of tiles, so the stash covers the same tile range whichever build runs
     a.nbatches = (n + 255) / 256 * (8 / a.waves);
     long long grid = (a.resident ? 2LL : 1LL) * num_cus();
@@ -144,6 +146,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
 }
 
 extern "C" int lfgc_forward_bf16(const lfgc_mlp_desc* desc, const lfgc_positions* positions, const float* grid_cl, int D, int H,
-                                 int W, const float* packed, int clamp, float* out, float* stash, lfgc_stream_t stream) {
-    return lfgc_forward_f32(desc, positions, grid_cl, D, H, W, packed, LFGC_PRECISION_F16, clamp, out, stash, nullptr, stream);
+                                 int W, const float* packed, int clamp, float* out, float* stash, int32_t* status,
+                                 lfgc_stream_t stream) {
+    return lfgc_forward_f32(desc, positions, grid_cl, D, H, W, packed, LFGC_PRECISION_F16, clamp, out, stash, status, stream);
 }

@@ -253,6 +253,44 @@ __device__ __forceinline__ void lfgc_dma_to_lds(const float* __restrict__ gsrc, 
     }
 }
 
+// The same copy cut into its 1-KiB pieces (one wave-instruction each) so that a caller can spread them over its own
+// instruction stream: piece `pi` of this wave = piece wave + pi * nwaves of the block.  A wave that issues its 8-9 pieces
+// of a 68-KB layer block back to back -- as every wave of the workgroup does at the same moment after the layer's
+// barrier -- queues behind the CU's one texture-address path: measured ~170 cycles per piece, 1.4 k cycles per wave and
+// layer (profiles/r3/stamps_w8_before.log: layer time - 96 x 64).  One piece every few MFMA gaps issues in the matrix
+// pipe's shadow instead (lfgc_dma_piece below).  (Requesting the pieces in a different order per CU -- so that the CUs of an XCD do not ask the
+// L2 for the same line at once -- was measured too: 2.7 % SLOWER, profiles/r3/ab_epilogue_dma.log.)
+// Branch-free on purpose (a predicated piece would cut the caller's MFMA stream into basic blocks): a piece index past
+// the end of the block, and the partial last piece, are clamped onto the block's last 64 vectors -- the same bytes to
+// the same LDS addresses again, harmless -- and a plan always names a real block (when no batch follows, the caller
+// lets the unused slot be filled once more).
+struct LfgcDmaPlan {
+    const float* src;     // global block
+    float* dst;           // LDS block (same layout)
+    int nvec;             // 16-byte vectors in the block (>= 64)
+    int wave;             // wave-uniform (readfirstlane)
+    unsigned lane16;      // lane * 16
+};
+template <int NWAVES>
+__device__ __forceinline__ void lfgc_dma_piece(const LfgcDmaPlan& d, int pi) {
+    int base = (d.wave + pi * NWAVES) << 6;              // wave-uniform
+    base = base < d.nvec - 64 ? base : d.nvec - 64;
+    const unsigned long long ga = (unsigned long long)(size_t)(d.src + 4 * base);
+    // (wave-uniform by construction; readfirstlane makes it so for the register allocator where it cannot prove it)
+    const unsigned long long sp = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ga) |
+                                  ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ga >> 32)) << 32);
+    const unsigned lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(d.dst + 4 * base));   // low half of the flat address = LDS offset
+    // Written out: the builtin is given a 64-bit per-lane address, and hipcc then keeps one VGPR pair per piece alive
+    // across the whole batch loop (spilled, and reloaded behind an s_waitcnt vmcnt(0) in the middle of the MFMA stream).
+    // This form takes the block address from SGPRs and one 32-bit lane offset that never changes.  M0 is not named as a
+    // clobber (hipcc reserves it); nothing else in the kernels that use this sets M0 except the builtin form of the same
+    // instruction, which writes M0 itself right before each use.
+#ifndef LFGC_DMA_POLICY
+#define LFGC_DMA_POLICY ""
+#endif
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" LFGC_DMA_POLICY :: "s"(lds_addr), "v"(d.lane16), "s"(sp) : "memory");
+}
+
 // d SnakeAlt / da = 0.5 + 2 sin a cos a
 template <bool WIDE>
 __device__ __forceinline__ float lfgc_snake_grad_t(float a) {

@@ -84,60 +84,110 @@ __device__ __forceinline__ void lfgc_cvt8(const float* __restrict__ x, h16x8& hi
     hi = __builtin_bit_cast(h16x8, hp);
 }
 
-// Activation + hand-over of one finished 32-row output tile, cut into 8 accumulator pairs x 3 stages ("slots") so
-// that a slot fits the shadow of one MFMA.  Pair P = accumulator registers 2P, 2P+1 = rows 32m + 8(P>>1) + 4hh +
-// 2(P&1) + {0,1} of the lane's sample; it becomes 32-bit element P&3 of output fragment P>>2 of the tile.
-//   stage 0: t = acc / scale + b/pi (fma), first cosine            [bias quads stream through LDS reads one quad ahead]
-//   stage 1: second cosine, first result
-//   stage 2: second result, hi/lo split | head contribution (LAST)
+// Activation + hand-over of one finished 32-row output tile: 8 accumulator pairs x 6 dependency LEVELS.  Pair P =
+// accumulator registers 2P, 2P+1 = rows 32m + 8(P>>1) + 4hh + 2(P&1) + {0,1} of the lane's sample; it becomes 32-bit
+// element P&3 of output fragment P>>2 of the tile.
+//   level 0: t = acc / scale + b/pi (2 fma)          [bias quads stream through LDS reads one quad ahead]
+//   level 1: cos(2 pi t) (2 v_cos_f32)
+//   level 2: bounded part (1 - cos)/2, scaled (2 fma)
+//   level 3: + linear part (2 fma)
+//   level 4: f16 hi pair (1 cvt_pk)                   | head: first product (LAST)
+//   level 5: f16 lo pair (2 fma_mix)                  | head: second product (LAST)
+// Every level depends on the one before it.  An in-order wave that issues them back to back waits out each result
+// (one wave per SIMD ran the layers at 62-73 cycles per MFMA gap that way, profiles/r3/stamps_w4_before.log), so the
+// levels of one pair go into CONSECUTIVE gaps and each gap carries levels of different pairs -- mutually independent
+// instructions -- on the schedule of lfgc_epilogue_gap below.
 // The bounded part (1 - cos)/2 = sin(a)^2 is formed first and the linear part added last: the only rounding at the
 // magnitude of the result is the final one, like the reference's own 0.5 a + sin(a)^2.
+#define LFGC_EP_LEVELS 6
 template <bool STASH, bool LAST, bool SPLIT>
 struct LfgcEpilogue {
     float inv_scale;
     const float* bias;        // LDS: b/pi of the tile's rows for this lane half (quad q at bias + 8 q)
     const float* wf;          // LDS: final-layer weights of the same rows (LAST)
     float* stash;             // this tile's stash rows for this lane, or nullptr
-    f32x4 bq[2], wq[2];
-    float t0, t1, c0, c1, h0, h1;
+    f32x4 bq[2], wq[4];
+    float t[8][2], v[8][2];   // per pair: pre-activation in turns; cos -> bounded part -> activation (in place)
+    unsigned hp[8];
 
-    __device__ __forceinline__ void begin() {                 // issue the first bias quad (call >= 1 gap before slot 0)
+    __device__ __forceinline__ void begin() {                 // issue the first bias quad (call >= 1 gap before level 0)
         bq[0] = *reinterpret_cast<const f32x4*>(bias);
-        if (LAST) wq[0] = *reinterpret_cast<const f32x4*>(wf);
-    }
-
-    template <int P, int S>
-    __device__ __forceinline__ void slot(const f32x16& acc, u32x4 (&Ohi)[2], u32x4 (&Olo)[2], float& ydot, float& tmax) {
-        constexpr int Q = P >> 1, I = 2 * (P & 1);
-        if constexpr (S == 0) {
-            if constexpr ((P & 1) == 0 && Q + 1 < 4) {
-                bq[(Q + 1) & 1] = *reinterpret_cast<const f32x4*>(bias + 8 * (Q + 1));
-                if (LAST) wq[(Q + 1) & 1] = *reinterpret_cast<const f32x4*>(wf + 8 * (Q + 1));
-            }
-            t0 = __builtin_fmaf(acc[2 * P], inv_scale, bq[Q & 1][I]);
-            t1 = __builtin_fmaf(acc[2 * P + 1], inv_scale, bq[Q & 1][I + 1]);
-            c0 = __builtin_amdgcn_cosf(t0);                              // cos(2 pi t)
-            if (STASH) {                                                  // the backward kernels read a = pi t
-                stash[(2 * P) * 64] = t0 * 3.14159274101257324f;
-                stash[(2 * P + 1) * 64] = t1 * 3.14159274101257324f;
-            }
-            if (LAST) tmax = lfgc_absmax3(tmax, t0, t1);
-        } else if constexpr (S == 1) {
-            c1 = __builtin_amdgcn_cosf(t1);
-            h0 = __builtin_fmaf(t0, LFGC_ACT_C, __builtin_fmaf(c0, -LFGC_ACT_HALF, LFGC_ACT_HALF));     // scaled, also for the head
-        } else {
-            h1 = __builtin_fmaf(t1, LFGC_ACT_C, __builtin_fmaf(c1, -LFGC_ACT_HALF, LFGC_ACT_HALF));
-            if (LAST) {       // fp32 head on the scaled activations (its weights carry 1 / LFGC_ACT_SCALE)
-                ydot = __builtin_fmaf(wq[Q & 1][I], h0, ydot);
-                ydot = __builtin_fmaf(wq[Q & 1][I + 1], h1, ydot);
-            } else {
-                const unsigned hp = lfgc_cvt_pk(h0, h1);
-                Ohi[P >> 2][P & 3] = hp;
-                if (SPLIT) Olo[P >> 2][P & 3] = lfgc_lo_pk(hp, h0, h1);
-            }
+        if (LAST) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wq[q] = *reinterpret_cast<const f32x4*>(wf + 8 * q);
         }
     }
+
+    template <int P, int LV>
+    __device__ __forceinline__ void level(const f32x16& acc, u32x4 (&Ohi)[2], u32x4 (&Olo)[2], float& ydot, float& tmax) {
+        constexpr int Q = P >> 1, I = 2 * (P & 1);
+        if constexpr (LV == 0) {
+            if constexpr ((P & 1) == 0 && Q + 1 < 4) bq[(Q + 1) & 1] = *reinterpret_cast<const f32x4*>(bias + 8 * (Q + 1));
+            t[P][0] = __builtin_fmaf(acc[2 * P], inv_scale, bq[Q & 1][I]);
+            t[P][1] = __builtin_fmaf(acc[2 * P + 1], inv_scale, bq[Q & 1][I + 1]);
+            if (STASH) {                                                  // the backward kernels read a = pi t
+                stash[(2 * P) * 64] = t[P][0] * 3.14159274101257324f;
+                stash[(2 * P + 1) * 64] = t[P][1] * 3.14159274101257324f;
+            }
+            if (LAST) tmax = lfgc_absmax3(tmax, t[P][0], t[P][1]);
+        } else if constexpr (LV == 1) {
+            v[P][0] = __builtin_amdgcn_cosf(t[P][0]);                    // cos(2 pi t)
+            v[P][1] = __builtin_amdgcn_cosf(t[P][1]);
+        } else if constexpr (LV == 2) {
+            v[P][0] = __builtin_fmaf(v[P][0], -LFGC_ACT_HALF, LFGC_ACT_HALF);
+            v[P][1] = __builtin_fmaf(v[P][1], -LFGC_ACT_HALF, LFGC_ACT_HALF);
+        } else if constexpr (LV == 3) {
+            v[P][0] = __builtin_fmaf(t[P][0], LFGC_ACT_C, v[P][0]);      // scaled, also for the head
+            v[P][1] = __builtin_fmaf(t[P][1], LFGC_ACT_C, v[P][1]);
+        } else if constexpr (LV == 4) {
+            if (LAST) {       // fp32 head on the scaled activations (its weights carry 1 / LFGC_ACT_SCALE)
+                ydot = __builtin_fmaf(wq[Q][I], v[P][0], ydot);
+            } else {
+                hp[P] = lfgc_cvt_pk(v[P][0], v[P][1]);
+                Ohi[P >> 2][P & 3] = hp[P];
+            }
+        } else {
+            if (LAST) ydot = __builtin_fmaf(wq[Q][I + 1], v[P][1], ydot);
+            else if (SPLIT) Olo[P >> 2][P & 3] = lfgc_lo_pk(hp[P], v[P][0], v[P][1]);
+        }
+    }
+
+    // Everything at once, level-major (no MFMAs to ride under: the last tile of the last layer, or nets of two k-steps).
+    __device__ __forceinline__ void all(const f32x16& acc, u32x4 (&Ohi)[2], u32x4 (&Olo)[2], float& ydot, float& tmax) {
+        lfgc_static_for<LFGC_EP_LEVELS>([&](auto lv_c) {
+            lfgc_static_for<8>([&](auto p_c) {
+                this->template level<decltype(p_c)::value, decltype(lv_c)::value>(acc, Ohi, Olo, ydot, tmax);
+            });
+        });
+    }
 };
+
+// The slice of a pending epilogue that rides in gap g of GA.  Gap 0 only issues the first bias read (the accumulator's
+// last MFMA has just been issued: reading it at once would wait out the matrix pipe, and the bias its LDS latency); the
+// levels run on time steps tau = 0 .. T-1 (T = max(GA - 1, 6)): pair P runs its level lv at tau = s_P + lv with the
+// pairs' starts s_P = (T - 6) P / 7 spread over the tile, and step tau belongs to gap 1 + tau (GA - 1) / T -- with
+// GA >= 7 one step per gap (the levels of a pair in consecutive gaps, a gap holding the levels of up to three pairs),
+// fewer gaps take several steps each.  GA = 1: everything in the one gap.
+template <int GA, int g, class EPI>
+__device__ __forceinline__ void lfgc_epilogue_gap(EPI& ep, const f32x16& eacc, u32x4 (&Ehi)[2], u32x4 (&Elo)[2],
+                                                  float& ydot, float& tmax) {
+    if constexpr (g == 0) ep.begin();
+    if constexpr (GA == 1) {
+        ep.all(eacc, Ehi, Elo, ydot, tmax);
+    } else if constexpr (g > 0) {
+        constexpr int GE = GA - 1, ge = g - 1;
+        constexpr int T = GE > LFGC_EP_LEVELS ? GE : LFGC_EP_LEVELS;
+        constexpr int tau_lo = (ge * T + GE - 1) / GE, tau_hi = ((ge + 1) * T + GE - 1) / GE;
+        lfgc_static_for<tau_hi - tau_lo>([&](auto d_c) {
+            constexpr int tau = tau_lo + decltype(d_c)::value;
+            lfgc_static_for<8>([&](auto p_c) {
+                constexpr int P = decltype(p_c)::value;
+                constexpr int lv = tau - (T - LFGC_EP_LEVELS) * P / 7;
+                if constexpr (lv >= 0 && lv < LFGC_EP_LEVELS) ep.template level<P, lv>(eacc, Ehi, Elo, ydot, tmax);
+            });
+        });
+    }
+}
 
 // A-operand queue: the fragments of the next LFGC_PF k-steps, read from LDS that many k-steps ahead of their MFMAs.
 #ifndef LFGC_PF
@@ -149,15 +199,18 @@ struct LfgcOperands {
 
 // The gaps of one output tile: G = KS16 * (SPLIT ? 3 : 1) MFMAs accumulating into `acc` (started from 0: the bias is
 // added in the epilogue), each followed by the A-operand read of the next k-step (or of `arow_next`'s first) and by its
-// slice of the pending epilogue `ep` of accumulator `eacc` (24 slots spread over the first GA gaps; GA = 0: nothing
+// slice of the pending epilogue `ep` of accumulator `eacc` (lfgc_epilogue_gap: spread over the first GA gaps; GA = 0: nothing
 // pending).  The epilogue writes fragments Ehi / Elo; when these are IN's own last two (a tile carried over from the
 // previous layer, GA = gaps of the first KS16 - 2 k-steps) they are copied into IN before k-step KS16 - 2 reads them.
 // `w` holds the operands of this tile's first LFGC_PF k-steps on entry and of the next tile's on exit.
-template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, class EPI>
+// Weight streaming: the NP pieces this wave owes of the NEXT block (lfgc_dma_piece; NP = 0: resident build) are
+// requested one at a time in gaps DG0 + g < DSPAN of the layer, evenly spread.
+template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, int NP, int DG0, int DSPAN, int WAVES, class EPI>
 __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, const float* __restrict__ arow_next,
                                                u32x4 (&INhi)[KS16], u32x4 (&INlo)[KS16], f32x16& acc,
                                                LfgcOperands& w, EPI& ep, const f32x16& eacc,
-                                               u32x4 (&Ehi)[2], u32x4 (&Elo)[2], float& ydot, float& tmax) {
+                                               u32x4 (&Ehi)[2], u32x4 (&Elo)[2], float& ydot, float& tmax,
+                                               const LfgcDmaPlan& dma) {
     constexpr int MPK = SPLIT ? 3 : 1;
     static_assert(!E_IS_IN_TAIL || GA <= (KS16 - 2) * MPK, "a carried tile must be done before the k-steps that read it");
 #pragma unroll
@@ -182,6 +235,12 @@ __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, c
             } else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh, acc, 0, 0, 0);
             }
+            if constexpr (NP > 0) {          // this gap's share of the weight stream, in the MFMA's shadow
+                constexpr int gg = DG0 + g;
+                constexpr int pi_lo = gg < DSPAN ? (gg * NP + DSPAN - 1) / DSPAN : NP;
+                constexpr int pi_hi = gg + 1 < DSPAN ? ((gg + 1) * NP + DSPAN - 1) / DSPAN : NP;
+                lfgc_static_for<(gg < DSPAN ? pi_hi - pi_lo : 0)>([&](auto p_c) { lfgc_dma_piece<WAVES>(dma, pi_lo + decltype(p_c)::value); });
+            }
             // the operands of k-step ks + LFGC_PF (running on into the next tile's rows), one read per gap
             const float* nsrc = (ks + LFGC_PF < KS16) ? arow + 16 * (ks + LFGC_PF)
                                                       : (arow_next ? arow_next + 16 * (ks + LFGC_PF - KS16) : nullptr);
@@ -191,13 +250,8 @@ __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, c
                 if (SPLIT && u == 1) nlo = *reinterpret_cast<const h16x8*>(nsrc + 4);
             }
 #endif
-            if constexpr (GA > 0 && g < GA && !(LFGC_ABLATE & 16)) {      // diagnostics: 16 = no epilogue under the MFMAs
-                constexpr int s_lo = g * 24 / GA, s_hi = (g + 1) * 24 / GA;
-                lfgc_static_for<s_hi - s_lo>([&](auto s_c) {
-                    constexpr int s = s_lo + decltype(s_c)::value;
-                    ep.template slot<s / 3, s % 3>(eacc, Ehi, Elo, ydot, tmax);
-                });
-            }
+            if constexpr (GA > 0 && g < GA && !(LFGC_ABLATE & 16))        // diagnostics: 16 = no epilogue under the MFMAs
+                lfgc_epilogue_gap<GA, g>(ep, eacc, Ehi, Elo, ydot, tmax);
             __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
@@ -217,14 +271,20 @@ struct LfgcCarry {
 // One hidden layer on a 32-sample tile.  IN = KS16 input fragments (the last two still owed by `carry` when
 // HAS_CARRY: they are produced under this layer's first MFMAs), OUT = this layer's 2*MT output fragments (all but the
 // last two; those are `out_carry`'s to produce), or with LAST the head's partial dot product in `ydot` (complete).
-template <int KS16, int MT, int S, bool STASH, bool LAST, bool SPLIT, bool HAS_CARRY>
+template <int KS16, int MT, int S, bool STASH, bool LAST, bool SPLIT, bool HAS_CARRY, int NP, int WAVES>
 __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk, u32x4 (&INhi)[KS16], u32x4 (&INlo)[KS16],
                                                  const LfgcCarry& carry, float inv_scale, const float* __restrict__ s_bias,
                                                  u32x4 (&OUThi)[2 * MT], u32x4 (&OUTlo)[2 * MT], LfgcCarry& out_carry,
                                                  const float* __restrict__ s_final, float& ydot, float& tmax,
-                                                 float* __restrict__ stash, int j, int hh, int lane) {
+                                                 float* __restrict__ stash, int j, int hh, int lane, const LfgcDmaPlan& dma) {
     constexpr int MPK = SPLIT ? 3 : 1;
     constexpr int G = KS16 * MPK;
+    // the next block's pieces go out over the first 3/4 of the layer's gaps: the last one then has a quarter of the layer
+    // to land before the wave waits for it at the next barrier
+#ifndef LFGC_DMA_SPAN4
+#define LFGC_DMA_SPAN4 3
+#endif
+    constexpr int DSPAN = (MT * G * LFGC_DMA_SPAN4 + 3) / 4;
     const float* s_row = s_blk + j * S + 8 * hh;              // lane half hh: bytes [32 hh, 32 hh + 32) of each 64-B k-step
     const float* bias_l = s_bias + 4 * hh;
     const float* wf_l = s_final + 4 * hh;
@@ -245,17 +305,14 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
         constexpr int GA0 = HAS_CARRY ? (KS16 - 2) * MPK : 0;
         if (HAS_CARRY) {
             ep.inv_scale = carry.inv_scale; ep.bias = carry.bias; ep.wf = nullptr; ep.stash = carry.stash;
-            ep.begin();
             if constexpr (GA0 == 0) {      // two k-steps in all (H <= 32): both read the owed fragments, nothing to hide under
-                lfgc_static_for<24>([&](auto s_c) {
-                    constexpr int s = decltype(s_c)::value;
-                    ep.template slot<s / 3, s % 3>(carry.acc, ehi, elo, ydot, tmax);
-                });
+                ep.begin();
+                ep.all(carry.acc, ehi, elo, ydot, tmax);
                 INhi[KS16 - 2] = ehi[0]; INhi[KS16 - 1] = ehi[1]; INlo[KS16 - 2] = elo[0]; INlo[KS16 - 1] = elo[1];
             }
         }
-        lfgc_tile_gaps<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0)>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo, accs[0], w,
-                                                    ep, carry.acc, ehi, elo, ydot, tmax);
+        lfgc_tile_gaps<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0), NP, 0, DSPAN, WAVES>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo,
+                                                    accs[0], w, ep, carry.acc, ehi, elo, ydot, tmax, dma);
     }
     // tiles 1 .. MT-1: each shadows the tile before it
     lfgc_static_for<MT - 1>([&](auto m_c) {
@@ -263,10 +320,9 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
         LfgcEpilogue<STASH, LAST, SPLIT> ep;
         ep.inv_scale = inv_scale; ep.bias = bias_l + 32 * (m - 1); ep.wf = wf_l + 32 * (m - 1);
         ep.stash = STASH ? stash_l + (m - 1) * (16 * 64) : nullptr;
-        ep.begin();
         u32x4 ehi[2], elo[2];
-        lfgc_tile_gaps<KS16, SPLIT, G, false>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr, INhi, INlo,
-                                              accs[m & 1], w, ep, accs[(m - 1) & 1], ehi, elo, ydot, tmax);
+        lfgc_tile_gaps<KS16, SPLIT, G, false, NP, m * G, DSPAN, WAVES>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr,
+                                              INhi, INlo, accs[m & 1], w, ep, accs[(m - 1) & 1], ehi, elo, ydot, tmax, dma);
         if (!LAST) {
             OUThi[2 * (m - 1)] = ehi[0]; OUThi[2 * (m - 1) + 1] = ehi[1];
             OUTlo[2 * (m - 1)] = elo[0]; OUTlo[2 * (m - 1) + 1] = elo[1];
@@ -279,10 +335,7 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
         ep.stash = STASH ? stash_l + (MT - 1) * (16 * 64) : nullptr;
         u32x4 ehi[2], elo[2];
         ep.begin();
-        lfgc_static_for<24>([&](auto s_c) {
-            constexpr int s = decltype(s_c)::value;
-            ep.template slot<s / 3, s % 3>(accs[(MT - 1) & 1], ehi, elo, ydot, tmax);
-        });
+        ep.all(accs[(MT - 1) & 1], ehi, elo, ydot, tmax);
     } else {
         out_carry.acc = accs[(MT - 1) & 1];
         out_carry.inv_scale = inv_scale;
@@ -315,6 +368,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     constexpr int BLK1 = HP * S1 + HP;
     constexpr int BLKMAX = BLK0 > BLK1 ? BLK0 : BLK1;
     constexpr int NT = WAVES * 64;
+    // 1-KiB DMA pieces per wave for a hidden layer's block (streamed under the layer before it) and for layer 0's (under
+    // the last layer of the batch before)
+    constexpr int NP1 = STREAM ? ((BLK1 / 4 + 63) / 64 + WAVES - 1) / WAVES : 0;
+    constexpr int NP0 = STREAM ? ((BLK0 / 4 + 63) / 64 + WAVES - 1) / WAVES : 0;
     // offsets inside the packed blob (lfgc_common.h)
     constexpr int F_BLK0 = HP * (K0P + 4) + HP, F_BLK1 = HP * (HP + 4) + HP;
     constexpr int K0R = (K0P + 31) / 32 * 32;
@@ -329,13 +386,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);      // the same number, known to be wave-uniform
     const int j = lane & 31;
     const int hh = lane >> 5;
     const int L = a.L;
     const int off_final = F_BLK0 + (L - 1) * F_BLK1;
     const int off_h = off_final + HP + 4 + K0R * (HP + 4) + (L - 1) * HP * (HP + 4);
     const float* hblk = a.packed + off_h + 32 + LFGC_MAX_LAYERS * HP + HP;
-
     {
         // head: weights divided by LFGC_ACT_SCALE (the last hidden layer's activations arrive scaled), bias as it is
         for (int i = tid; i < HP; i += NT) s_final[i] = a.packed[off_h + 32 + LFGC_MAX_LAYERS * HP + i];
@@ -388,6 +445,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
         LfgcSampler<CH, NF> sampler;
         sampler.issue(a, nc, N, s_coord, hh);           // 8 corner rows requested; used after the layer-0 barrier
 
+        LfgcDmaPlan dma = {hblk, s_w, BLK0 / 4, wave_s, (unsigned)lane * 16u};
+        // opaque per batch: otherwise the address arithmetic of every piece of every block is hoisted out of this loop
+        // into ~60 SGPRs that do not exist (spilled to VGPR lanes, v_readlane in the gaps)
+        asm volatile("" : "+s"(dma.wave));
         auto acquire = [&](int l) -> const float* {
             if (!STREAM) return s_w + (l == 0 ? 0 : BLK0 + (l - 1) * BLK1);
             LFGC_STAMP(2 + 2 * (l < 6 ? l : 6));           // the layer before this acquire (or the input phase for l = 0 -> slot 1 below)
@@ -405,11 +466,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             __syncthreads();
             LFGC_STAMP(3 + 2 * (l < 5 ? l : 5));            // barrier before layer l
             const float* blk = s_w + (step & 1) * BLKMAX;
+            // the next block (the layer after this one, or layer 0 of the next batch) goes into the other ring slot -- every
+            // wave is past the barrier, so nobody reads it any more -- piece by piece under this layer's MFMAs
+            // (after the last batch the slot is filled once more for nobody: an unconditional stream keeps the gaps
+            // free of branches)
             const int ln = (l + 1 == L) ? 0 : l + 1;
-            if (ln != 0 || batch + gridDim.x < a.nbatches) {
-                const float* src = hblk + (ln == 0 ? 0 : BLK0 + (long long)(ln - 1) * BLK1);
-                lfgc_dma_to_lds(src, s_w + ((step + 1) & 1) * BLKMAX, ln == 0 ? BLK0 : BLK1, wave, lane, WAVES);
-            }
+            dma.src = hblk + (ln == 0 ? 0 : BLK0 + (long long)(ln - 1) * BLK1);
+            dma.dst = s_w + ((step + 1) & 1) * BLKMAX;
+            dma.nvec = (ln == 0 ? BLK0 : BLK1) / 4;
             ++step;
             return blk;
         };
@@ -450,35 +514,35 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             const float* blk = acquire(0);
 #endif
             if (L == 1)
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT, false>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
-                                                                            s_final, ydot, tmax, stash_of(0), j, hh, lane);
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT, false, NP0, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                                                                            s_final, ydot, tmax, stash_of(0), j, hh, lane, dma);
             else
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false, SPLIT, false>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
-                                                                             s_final, ydot, tmax, stash_of(0), j, hh, lane);
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false, SPLIT, false, NP1, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                                                                             s_final, ydot, tmax, stash_of(0), j, hh, lane, dma);
         }
         // hidden layers 1 .. L-2 in ping-pong pairs, then the last one with the head folded in
         {
             int l = 1;
             for (; l + 2 < L; l += 2) {
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
-                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
                 blk = acquire(l + 1);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true>(blk, Bhi, Blo, cb, s_scale[9 + l], s_bias + (l + 1) * HP, Ahi, Alo, ca,
-                                                                            s_final, ydot, tmax, stash_of(l + 1), j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, WAVES>(blk, Bhi, Blo, cb, s_scale[9 + l], s_bias + (l + 1) * HP, Ahi, Alo, ca,
+                                                                            s_final, ydot, tmax, stash_of(l + 1), j, hh, lane, dma);
             }
             if (l + 1 < L) {       // one more non-final layer: A -> B, final consumes B
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
-                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
                 ++l;
                 blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true>(blk, Bhi, Blo, cb, s_scale[8 + l], s_bias + l * HP, Ahi, Alo, ca,
-                                                                           s_final, ydot, tmax, stash_of(l), j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true, NP0, WAVES>(blk, Bhi, Blo, cb, s_scale[8 + l], s_bias + l * HP, Ahi, Alo, ca,
+                                                                           s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
             } else if (l < L) {    // final layer consumes A
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
-                                                                           s_final, ydot, tmax, stash_of(l), j, hh, lane);
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true, NP0, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                                                                           s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
             }
         }
 
@@ -495,6 +559,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
         if (a.clamp) y = fminf(fmaxf(y, -1.0f), 1.0f);
         if (valid && hh == 0) a.out[n] = y;
     }
+    // the stream's last block (fetched for nobody) must have landed before the workgroup gives its LDS back
+    if (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef LFGC_STAMPS
     if (a.stamps && lane == 0) {
         unsigned long long* dst = a.stamps + ((long long)blockIdx.x * WAVES + wave) * 20;

@@ -404,3 +404,76 @@ def test_finite_difference_gradient_of_the_gt_sampler(dev):
     assert np.array_equal(got.cpu().numpy(), g['grad'])
     got = finite_difference_trilinear_grad(p, vol, mn, mx, rs, scale=torch.from_numpy(g['scale']))
     assert np.array_equal(got.cpu().numpy(), g['grad_scaled'])
+
+
+def test_graph_replayed_train_step_matches_eager_steps(dev):
+    """The cfg-3 train step bench.py times is ONE captured HIP graph replayed (bench.capture_train_step).  Replays must
+    do what eager steps do: same Philox batches (the draw counter lives on the device and advances per replay), same
+    forward / loss / backward / fused Adam.  Run A = 3 eager warm-up steps + capture + K replays (exactly bench.py's
+    sequence), run B = 3 + K eager steps of an identically built model; compared after the last step:
+      * MLP weights and biases: max|A - B| <= 1e-5 of each tensor's largest entry (their gradients are bitwise
+        repeatable given the same inputs; the inputs differ in the last bits through the coefficients),
+      * wavelet coefficients: grid gradients are float-atomic sums (order-dependent in the last bits) and Adam's
+        first steps move an entry by ~lr g/|g|, so an entry whose gradient is rounding noise can move either way:
+        <= 1e-4 of the tensor's largest entry for all but 1e-4 of the entries, and never by more than 2 lr K;
+      * the per-step losses of B against the losses A's replays wrote (same batches): 1e-5 relative;
+      * step 1's gradients (run B) against the oracle's autograd on the same batch and ground truth: 2e-5."""
+    import bench
+    K, warm, lr = 5, 3, 0.008
+    ctx_a = bench.cfg3_train_setup(dev, 'f16x2')
+    graph, loss_a, eager_a = bench.capture_train_step(ctx_a, eager_warmup=warm)
+    replay_losses = []
+    for _ in range(K):
+        graph.replay()
+        replay_losses.append(float(loss_a.detach()))          # .item() synchronises: the replay is done
+    torch.cuda.synchronize()
+    assert ctx_a['ds']._sample_state.cpu().tolist() == [warm + K, 0]          # capture itself drew nothing
+
+    ctx_b = bench.cfg3_train_setup(dev, 'f16x2')
+    mb = ctx_b['model']
+    for (ka, pa), (kb, pb) in zip(ctx_a['model'].named_parameters(), mb.named_parameters()):
+        assert ka == kb and pa.shape == pb.shape
+    start = {k: p.detach().clone() for k, p in mb.named_parameters()}
+    losses_b, step1 = [], None
+    for i in range(warm + K):
+        losses_b.append(float(ctx_b['step']().detach()))
+        if i == 0:
+            raw1, norm1 = (t.detach().clone() for t in ctx_b['last_batch'])
+            step1 = {k: p.grad.detach().clone() for k, p in mb.named_parameters()}
+    torch.cuda.synchronize()
+    assert ctx_b['ds']._sample_state.cpu().tolist() == [warm + K, 0]
+    for i in range(warm):
+        assert abs(float(eager_a[i]) - losses_b[i]) <= 1e-5 * abs(losses_b[i]), (i, float(eager_a[i]), losses_b[i])
+    for i in range(K):
+        assert abs(replay_losses[i] - losses_b[warm + i]) <= 1e-5 * abs(losses_b[warm + i]), (i, replay_losses[i], losses_b[warm + i])
+    assert losses_b[-1] < losses_b[0]                      # the smooth volume is learnable: the optimizer does something
+    moved = 0.0
+    for (k, pa), (_, pb) in zip(ctx_a['model'].named_parameters(), mb.named_parameters()):
+        a, b = pa.detach().cpu().numpy().astype(np.float64), pb.detach().cpu().numpy().astype(np.float64)
+        moved = max(moved, float(np.abs(b - start[k].cpu().numpy()).max()))
+        d, top = np.abs(a - b), np.abs(b).max()
+        if k.startswith('feature_grid'):
+            assert d.max() <= 2 * lr * (warm + K) * (1 + 1e-3), k
+            assert float((d > 1e-4 * top).mean()) <= 1e-4, (k, float((d > 1e-4 * top).mean()), d.max(), top)
+        else:
+            assert d.max() <= 1e-5 * top, (k, d.max(), top)
+    assert moved > lr                                      # parameters did move
+    # step 1 of run B against the oracle's autograd (same batch, ground truth from the oracle's own sampler)
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    sd = {k: v.cpu() for k, v in start.items()}
+    nc, L = len(mb.feature_grid), mb.num_layer
+    coeffs = [sd['feature_grid.%d' % i].clone().requires_grad_(True) for i in range(nc)]
+    ws = [sd['net_layers.%d.weight' % i].clone().requires_grad_(True) for i in range(L)] + [sd['final_layer.weight'].clone().requires_grad_(True)]
+    bs = [sd['net_layers.%d.bias' % i].clone().requires_grad_(True) for i in range(L)] + [sd['final_layer.bias'].clone().requires_grad_(True)]
+    mn, mx, rs = (torch.tensor(v, dtype=torch.float32) for v in ctx_b['bounds'])
+    gt = R.trilinear_f_interpolation(raw1.cpu(), ctx_b['vol'].cpu(), mn, mx, rs)
+    yr = R.forward(coeffs, mb.shape_array, mb.filter.filter_rev.detach().cpu(), ws, bs, norm1.cpu(), 2, training=True)
+    lr_ = torch.nn.functional.mse_loss(yr.squeeze(-1), gt)
+    lr_.backward()
+    assert abs(losses_b[0] - lr_.item()) <= 1e-5 * abs(lr_.item())
+    ref = {'feature_grid.%d' % i: c.grad.numpy() for i, c in enumerate(coeffs)}
+    for i in range(L):
+        ref['net_layers.%d.weight' % i], ref['net_layers.%d.bias' % i] = ws[i].grad.numpy(), bs[i].grad.numpy()
+    ref['final_layer.weight'], ref['final_layer.bias'] = ws[L].grad.numpy(), bs[L].grad.numpy()
+    for k, g in step1.items():
+        assert rel_err(g.cpu().numpy(), ref[k]) <= 2e-5, k

@@ -228,8 +228,12 @@ def test_reduced_precision_entry_points_are_the_f16_mode(dev):
     stash = torch.empty_like(stash_w)
     st = torch.cuda.current_stream().cuda_stream
     assert lib.lfgc_forward_bf16(ctypes.byref(desc), ctypes.byref(ps), grid.data_ptr(), D, H, W, packed.data_ptr(), 0,
-                                 out.data_ptr(), stash.data_ptr(), st) == 0
+                                 out.data_ptr(), stash.data_ptr(), None, st) == 0
     assert torch.equal(out, want) and torch.equal(stash, stash_w)
+    word = torch.full((1,), 7, dtype=torch.int32, device=dev)          # with a status word: cleared, stays clear, same result
+    assert lib.lfgc_forward_bf16(ctypes.byref(desc), ctypes.byref(ps), grid.data_ptr(), D, H, W, packed.data_ptr(), 0,
+                                 out.data_ptr(), stash.data_ptr(), word.data_ptr(), st) == 0
+    assert int(word.item()) == 0 and torch.equal(out, want) and torch.equal(stash, stash_w)
     weights, biases = m._mlp_params()
     d_y = torch.from_numpy(np.random.default_rng(3).standard_normal(n).astype(np.float32)).to(dev)
     w_grid, w_w, w_b, _ = ops.backward_raw(desc, grid, packed, pos, stash_w, d_y, weights, biases, False, precision='f16')
@@ -490,36 +494,61 @@ def _two_rank_worker(rank, world, port, out_dir):
     m, _ = build_synth(8, 16, 32, 2, seed=123, dev=dev)
     m.eval()
     ds = IndexDataset((100, 40, 36), 16, build_index_table=False)
+    res = {'full': V.field_from_net_fused(ds, m).cpu()}
+
+    # (1) reconstruct_volume_sharded itself on both ranks, slabs from the fused HIP kernel, collectives on host tensors
+    #     (gloo's native form): partition, pieces, in-place receives and both gather modes of the function under test.
+    def hip_slab_to_host(b, e, view):
+        view.copy_(V.field_from_net_fused(ds, m, b, e).cpu())
+    for mode in ('all', 'root'):
+        v = V.reconstruct_volume_sharded(ds, m, chunks=2, slab_fn=hip_slab_to_host, device=torch.device('cpu'), gather=mode)
+        res['host_' + mode] = v if v is not None else None
+    # (2) the same function with DEVICE tensors handed to the collective (what RCCL does on a multi-GPU node).  gloo may or
+    #     may not take device tensors in this build: recorded, never silently replaced by another code path.
     try:
-        vol = V.reconstruct_volume_sharded(ds, m, chunks=2)
-        how = 'device tensors'
-    except RuntimeError:                              # gloo build without CUDA all-gather: gather through host memory
-        parts = V.slab_partition(100, world, 32)
-        b, e = parts[rank]
-        mine = V.field_from_net_fused(ds, m, b, e).cpu()
-        pad = torch.zeros((max(pe - pb for pb, pe in parts), 40, 36))
-        pad[:e - b] = mine
-        outs = [torch.zeros_like(pad) for _ in range(world)]
-        dist.all_gather(outs, pad)
-        vol = torch.cat([o[:pe - pb] for o, (pb, pe) in zip(outs, parts)], 0)
-        how = 'host staging'
-    full = V.field_from_net_fused(ds, m)
-    torch.save({'vol': vol.cpu(), 'full': full.cpu(), 'how': how}, os.path.join(out_dir, 'r%d.pt' % rank))
+        res['device_all'] = V.reconstruct_volume_sharded(ds, m, chunks=2).cpu()
+        res['device_error'] = ''
+    except RuntimeError as exc:
+        res['device_all'] = None
+        res['device_error'] = '%s: %s' % (type(exc).__name__, str(exc)[:300])
+    torch.save(res, os.path.join(out_dir, 'r%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_reconstruction_two_ranks_share_the_gpu(dev, tmp_path):
-    """The multi-rank driver with the real fused kernels: two processes (gloo rendezvous) on the one GPU each
-    evaluate their x-slab; the assembled volume equals the single-launch volume bit for bit."""
+@pytest.fixture(scope='module')
+def two_rank_results(tmp_path_factory):
     import socket
     import torch.multiprocessing as mp
+    if not torch.cuda.is_available():
+        pytest.skip('needs the GPU')
+    out = tmp_path_factory.mktemp('two_ranks')
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    for r in range(2):
-        d = torch.load(os.path.join(str(tmp_path), 'r%d.pt' % r), weights_only=True)
-        assert torch.equal(d['vol'], d['full']), (r, d['how'])
-        print('rank %d assembled the volume through: %s' % (r, d['how']))
+    mp.spawn(_two_rank_worker, args=(2, port, str(out)), nprocs=2, join=True)
+    return [torch.load(os.path.join(str(out), 'r%d.pt' % r), weights_only=True) for r in range(2)]
+
+
+def test_sharded_reconstruction_two_ranks_share_the_gpu(dev, two_rank_results):
+    """reconstruct_volume_sharded with two processes (gloo rendezvous) on the one GPU: each rank's x-slab comes from the
+    fused HIP kernel, the pieces travel as host tensors; the volume the FUNCTION UNDER TEST assembles equals the
+    single-launch volume bit for bit -- on every rank for gather='all', on the root alone for gather='root'."""
+    for r, d in enumerate(two_rank_results):
+        assert torch.equal(d['host_all'], d['full']), r
+        if r == 0:
+            assert torch.equal(d['host_root'], d['full'])
+        else:
+            assert d['host_root'] is None
+
+
+def test_sharded_reconstruction_two_ranks_device_collective(dev, two_rank_results):
+    """The same with device tensors handed straight to the collective.  Skips -- explicitly, with the backend's own
+    message -- where this gloo build takes no device tensors; RCCL (which does) cannot put two ranks on one GPU, so on a
+    one-GPU box its path is covered at world size 1 (test_cfg4_volume_255_cubed_sharded_edge_tiles)."""
+    errs = [d['device_error'] for d in two_rank_results]
+    if any(errs):
+        pytest.skip('device-tensor collective unavailable with gloo here: ' + next(e for e in errs if e))
+    for r, d in enumerate(two_rank_results):
+        assert torch.equal(d['device_all'], d['full']), r
 
 
 def test_headline_volume_invariants(dev):
@@ -654,6 +683,37 @@ def test_default_precision_is_range_safe(dev, where):
     with torch.no_grad():
         _, _, st2 = ops.forward_raw(m2._descriptor(), m2._decoded_channel_last(), m2._packed(), pos=pos.to(dev), return_status=True)
     assert int(st2.item()) == 0
+
+
+def test_reduced_precision_entry_is_range_safe(dev):
+    """lfgc_forward_bf16 with a status word: a pass that leaves the f16 range (layer-2 pre-activations ~1e5 -- finite in
+    fp32 and in a true bfloat16 path) comes back finite and reference-equivalent through the predicated exact redo, and
+    the word reports it; without the word the same pass returns NaN for the samples it could not do."""
+    from latent_feature_grid_compression_amd import ops, _lib
+    C, G, H, L = 16, 16, 64, 4
+    m, sm = build_synth(C, G, H, L, seed=77, dev=dev)
+    with torch.no_grad():
+        m.net_layers[1].weight.mul_(3.0e4)
+        sm['weights'][1] = sm['weights'][1] * 3.0e4
+    pos = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, (3000, 3)).astype(np.float32))
+    yref = _oracle_forward(sm, pos)
+    assert np.isfinite(yref).all()
+    lib = _lib.load()
+    desc, grid, packed = m._descriptor(), m._decoded_channel_last().detach(), m._packed()
+    pd = pos.to(dev)
+    ps, n = ops._positions_struct(pd)
+    D, Hh, W, _ = grid.shape
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(n, device=dev)
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert lib.lfgc_forward_bf16(ctypes.byref(desc), ctypes.byref(ps), grid.data_ptr(), D, Hh, W, packed.data_ptr(), 0,
+                                 out.data_ptr(), None, word.data_ptr(), st) == 0
+    assert int(word.item()) == 1
+    y = out.cpu().numpy()
+    assert np.isfinite(y).all() and rel_err(y, yref) <= 1e-5              # the redo is the exact build
+    assert lib.lfgc_forward_bf16(ctypes.byref(desc), ctypes.byref(ps), grid.data_ptr(), D, Hh, W, packed.data_ptr(), 0,
+                                 out.data_ptr(), None, None, st) == 0
+    assert not np.isfinite(out.cpu().numpy()).all()                       # no word: flagged as NaN, never a finite wrong value
 
 
 def test_range_fallback_also_rewrites_the_training_stash(dev):

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, 'tools', 'microbench', 'ablate')
+OUT = os.environ.get('LFGC_AB_DIR') or os.path.join(ROOT, 'tools', 'microbench', 'ablate')
 LIB = os.path.join(OUT, 'liblfgc_stamps.so')
 
 if sys.argv[1] == 'build':
