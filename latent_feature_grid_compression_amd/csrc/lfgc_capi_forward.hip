@@ -96,6 +96,25 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     if (const char* e = getenv("LFGC_FWD_WAVES")) { if (!a.resident && (e[0] == '4' || e[0] == '8')) a.waves = e[0] - '0'; }   // diagnostics
     // always whole 256-sample groups of tiles, so the stash covers the same tile range whichever build runs
     a.nbatches = (n + 255) / 256 * (8 / a.waves);
+    // Lattice mode on the f16 builds: z-run tiles + column sampler (lfgc_forward.h) when the column a 32-voxel run touches
+    // is short (volume at least ~3x finer than the grid along z: every BASELINE full-volume shape) and fits the LDS left.
+    a.zrun = 0; a.nzc = 2; a.tiles_per_row = 1; a.ntiles = 0;
+    if (h16 && !a.pos && a.coord_table && !stash && !getenv("LFGC_NO_ZRUN")) {
+        const int nzc = (int)(31.0 * (double)D / (double)(a.res2 - 1) + 1e-3) + 3;
+        const long long rows = (long long)(positions->x_end - positions->x_begin) * a.res1;
+        const int tpr = (a.res2 + LFGC_TILE_SAMPLES - 1) / LFGC_TILE_SAMPLES;
+        const long long ntiles = rows * tpr;
+        const long long tbl4 = 4LL * (((long long)a.res0 + a.res1 + a.res2 + 3) & ~3LL) - 4LL * ((long long)a.res0 + a.res1 + a.res2);
+        const long long cap = a.resident ? 80 * 1024 : 160 * 1024;
+        const long long col = 4LL * 8 * nzc * p.CH;                  // sized for the 8-wave build
+        if (nzc <= 12 && ntiles < (1LL << 31) && lds_bytes + tbl4 + col <= cap) {
+            a.zrun = 1; a.nzc = nzc; a.tiles_per_row = tpr; a.ntiles = ntiles;
+            lds_bytes += (int)(tbl4 + col);
+            a.waves = (!a.resident && (ntiles + 7) / 8 >= num_cus()) ? 8 : 4;
+            if (const char* e = getenv("LFGC_FWD_WAVES")) { if (!a.resident && (e[0] == '4' || e[0] == '8')) a.waves = e[0] - '0'; }
+            a.nbatches = (ntiles + a.waves - 1) / a.waves;
+        }
+    }
     long long grid = (a.resident ? 2LL : 1LL) * num_cus();
     if (grid > a.nbatches) grid = a.nbatches;
     hipStream_t st = (hipStream_t)stream;
@@ -121,7 +140,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
         // Range fallback: the same pass on the exact-fp32 build, enqueued behind the fast one; its workgroups return
         // at once unless the fast kernel has set *status (a sample left the f16 range: diverged or very wide model).
         // No host synchronisation, graph-capturable; costs one empty launch when nothing overflowed.
-        a.status = nullptr; a.redo_if = status; a.single = 0;
+        a.status = nullptr; a.redo_if = status; a.single = 0; a.zrun = 0;
         const int all32 = p.off_final, max32 = p.blk0 > p.blk1 ? p.blk0 : p.blk1, fixed32 = p.HP + 4;
         a.resident = ((fixed32 + all32) * 4 <= 80 * 1024) ? 1 : 0;
         lds_bytes = (fixed32 + (a.resident ? all32 : 2 * max32)) * 4;

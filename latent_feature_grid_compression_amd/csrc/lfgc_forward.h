@@ -47,6 +47,10 @@ struct LfgcFwdArgs {
     int* status;               // f16 builds: set to 1 when a sample left the range of the fast arithmetic (or nullptr)
     const int* redo_if;        // exact build: run only if *redo_if != 0 (nullptr: always) -- the range fallback
     unsigned long long* stamps;   // diagnostics builds (-DLFGC_STAMPS, tools/phase_stamps.py): per-wave cycle totals per phase
+    // lattice mode, f16 builds: "z-run" tiles (LfgcColumnSampler): a wave's 32 samples are 32 consecutive z of ONE (x, y)
+    // row of the slab; tiles_per_row = ceil(res2 / 32), ntiles = rows * tiles_per_row, nzc = z cells a tile's column holds
+    int zrun, nzc, tiles_per_row;
+    long long ntiles;
 };
 
 // Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile
@@ -74,6 +78,75 @@ __device__ __forceinline__ float lfgc_lattice_coord(int v, int res, int tile, fl
     }
     const float nrm = __fsub_rn(__fmul_rn(2.0f, lin), 1.0f);
     return __fmul_rn(scale, nrm);
+}
+
+// Scalar inputs [p | sin f_k p | cos f_k p | 0 pad] of the lane's sample: a lane keeps only its half of the list
+// (E[0 .. EP/2) = entries [hh EP/2, (hh+1) EP/2)).
+template <int NF>
+__device__ __forceinline__ void lfgc_embed_inputs(float p0, float p1, float p2, int hh, float* __restrict__ E) {
+    constexpr int EE = 3 + 6 * NF;
+    constexpr int EP = (EE + 7) / 8 * 8;
+    constexpr int EPH = EP / 2;
+    constexpr int E_ = EE;
+
+        // ---- scalar inputs [p | sin f_k p | cos f_k p]: a lane keeps only its half of the list ---------------------
+        if constexpr (NF == 2) {
+            // e = [p0 p1 p2 s0x s0y s0z c0x c0y | c0z s1x s1y s1z c1x c1y c1z 0] (f0, f1 = 2 f0): lane half 0 needs sin/cos
+            // of f0 p, lane half 1 those of f1 p plus cos(f0 p2) -- three sincos of lane-half-dependent arguments and one
+            // cosine instead of six sincos per lane.  Arguments are formed as before (one fp32 product each).
+            const float f0 = lfgc_freq(0), f1 = lfgc_freq(1);
+            const float f = hh ? f1 : f0;
+            const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f), a3 = __fmul_rn(p2, f0);
+            const bool bad = lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2) |
+                             lfgc_trig_out_of_range(a3);
+            float sA, cA, sB, cB, sC, cC, sD, cD;
+            lfgc_sincosf_t<false>(a0, sA, cA);
+            lfgc_sincosf_t<false>(a1, sB, cB);
+            lfgc_sincosf_t<false>(a2, sC, cC);
+            cD = lfgc_cosf_t<false>(a3);
+            if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
+                lfgc_sincosf_t<true>(a0, sA, cA);
+                lfgc_sincosf_t<true>(a1, sB, cB);
+                lfgc_sincosf_t<true>(a2, sC, cC);
+                lfgc_sincosf_t<true>(a3, sD, cD);
+            }
+            const float lo[8] = {p0, p1, p2, sA, sB, sC, cA, cB};
+            const float hi[8] = {cD, sA, sB, sC, cA, cB, cC, 0.0f};
+#pragma unroll
+            for (int t = 0; t < EPH; ++t) E[t] = hh ? hi[t] : lo[t];
+        } else {
+            float e[EP];
+            e[0] = p0; e[1] = p1; e[2] = p2;
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                const float f = lfgc_freq(k);
+                const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f);
+                bad |= lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2);
+                float s, c;
+                lfgc_sincosf_t<false>(a0, s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
+                lfgc_sincosf_t<false>(a1, s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
+                lfgc_sincosf_t<false>(a2, s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
+            }
+            if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
+#pragma unroll
+                for (int k = 0; k < NF; ++k) {
+                    const float f = lfgc_freq(k);
+                    float s, c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p0, f), s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p1, f), s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
+                    lfgc_sincosf_t<true>(__fmul_rn(p2, f), s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
+                }
+            }
+#pragma unroll
+            for (int t = E_; t < EP; ++t) e[t] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < EPH; ++t) {
+                float lo = e[t], hi = e[EPH + t];
+                asm volatile("" : "+v"(lo), "+v"(hi));     // keep both in VGPRs: a select of two array slots would go to scratch
+                E[t] = hh ? hi : lo;
+            }
+        }
 }
 
 // Positions, trilinear gather and Fourier embedding for the lane's sample, in two phases so that the gather's 8 x CH/8
@@ -163,64 +236,7 @@ struct LfgcSampler {
     }
 
     __device__ __forceinline__ void finish(int hh, float (&B0)[CHH + EPH]) {
-        // ---- scalar inputs [p | sin f_k p | cos f_k p]: a lane keeps only its half of the list ---------------------
-        if constexpr (NF == 2) {
-            // e = [p0 p1 p2 s0x s0y s0z c0x c0y | c0z s1x s1y s1z c1x c1y c1z 0] (f0, f1 = 2 f0): lane half 0 needs sin/cos
-            // of f0 p, lane half 1 those of f1 p plus cos(f0 p2) -- three sincos of lane-half-dependent arguments and one
-            // cosine instead of six sincos per lane.  Arguments are formed as before (one fp32 product each).
-            const float f0 = lfgc_freq(0), f1 = lfgc_freq(1);
-            const float f = hh ? f1 : f0;
-            const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f), a3 = __fmul_rn(p2, f0);
-            const bool bad = lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2) |
-                             lfgc_trig_out_of_range(a3);
-            float sA, cA, sB, cB, sC, cC, sD, cD;
-            lfgc_sincosf_t<false>(a0, sA, cA);
-            lfgc_sincosf_t<false>(a1, sB, cB);
-            lfgc_sincosf_t<false>(a2, sC, cC);
-            cD = lfgc_cosf_t<false>(a3);
-            if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
-                lfgc_sincosf_t<true>(a0, sA, cA);
-                lfgc_sincosf_t<true>(a1, sB, cB);
-                lfgc_sincosf_t<true>(a2, sC, cC);
-                lfgc_sincosf_t<true>(a3, sD, cD);
-            }
-            const float lo[8] = {p0, p1, p2, sA, sB, sC, cA, cB};
-            const float hi[8] = {cD, sA, sB, sC, cA, cB, cC, 0.0f};
-#pragma unroll
-            for (int t = 0; t < EPH; ++t) B0[CHH + t] = hh ? hi[t] : lo[t];
-        } else {
-            float e[EP];
-            e[0] = p0; e[1] = p1; e[2] = p2;
-            bool bad = false;
-#pragma unroll
-            for (int k = 0; k < NF; ++k) {
-                const float f = lfgc_freq(k);
-                const float a0 = __fmul_rn(p0, f), a1 = __fmul_rn(p1, f), a2 = __fmul_rn(p2, f);
-                bad |= lfgc_trig_out_of_range(a0) | lfgc_trig_out_of_range(a1) | lfgc_trig_out_of_range(a2);
-                float s, c;
-                lfgc_sincosf_t<false>(a0, s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
-                lfgc_sincosf_t<false>(a1, s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
-                lfgc_sincosf_t<false>(a2, s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
-            }
-            if (__builtin_expect(__any(bad), 0)) {   // positions far outside [-1,1], inf or nan
-#pragma unroll
-                for (int k = 0; k < NF; ++k) {
-                    const float f = lfgc_freq(k);
-                    float s, c;
-                    lfgc_sincosf_t<true>(__fmul_rn(p0, f), s, c); e[3 + 6 * k + 0] = s; e[3 + 6 * k + 3] = c;
-                    lfgc_sincosf_t<true>(__fmul_rn(p1, f), s, c); e[3 + 6 * k + 1] = s; e[3 + 6 * k + 4] = c;
-                    lfgc_sincosf_t<true>(__fmul_rn(p2, f), s, c); e[3 + 6 * k + 2] = s; e[3 + 6 * k + 5] = c;
-                }
-            }
-#pragma unroll
-            for (int t = E; t < EP; ++t) e[t] = 0.0f;
-#pragma unroll
-            for (int t = 0; t < EPH; ++t) {
-                float lo = e[t], hi = e[EPH + t];
-                asm volatile("" : "+v"(lo), "+v"(hi));     // keep both in VGPRs: a select of two array slots would go to scratch
-                B0[CHH + t] = hh ? hi : lo;
-            }
-        }
+        lfgc_embed_inputs<NF>(p0, p1, p2, hh, B0 + CHH);
         // ---- the 8 corner rows, accumulated in ATen's corner order -----------------------------------
         float feat[CHH];
 #pragma unroll
@@ -238,6 +254,101 @@ struct LfgcSampler {
         }
 #pragma unroll
         for (int c = 0; c < CHH; ++c) B0[c] = feat[c];
+    }
+};
+
+// Lattice mode, "z-run" tiles: the 32 samples of a wave are 32 consecutive z voxels of ONE (x, y) row of the volume, so
+// they share their x and y cells and weights and together touch only a short COLUMN of the grid: the cells
+// zc_lo .. zc_lo + nzc - 1 along z at the four (x, y) corners (nzc = floor(31 D / (res2 - 1)) + 3: 10 cells of the 64-cell
+// axis for a 256-voxel row, against 32 samples x 8 corner rows read one by one by LfgcSampler).  The wave
+//   stage_a: forms the positions and ATen's weights as LfgcSampler does, then -- 64 lanes = cells x 4-channel quads --
+//            loads the four (x, y) corner rows of every cell of the column (4 x dwordx4 per lane and pass instead of 32),
+//            contracts them with the x-y weights (ATen's corner order nw, ne, sw, se; the z weight is applied afterwards,
+//            once per plane: a different but equally short rounding sequence) and leaves the column in LDS;
+//   stage_b: every lane reads the two planes of ITS sample back (2 x CH/8 ds_read_b128) and applies the z weights.
+// 16 + 32 FMAs per lane instead of 128, 4-8 vector loads per lane instead of 32, and the loads go out once per cell
+// instead of once per sample: the texture-address path, which the 8 waves of a workgroup used to fill for 4 k cycles per
+// batch (32 x 8 x 1 KiB through 64 B / clock), is nearly idle.  Lanes whose cell index lies past the column redo one of
+// its cells (same value to the same LDS address): no lane predicate, no branch.
+template <int CH, int NF>
+struct LfgcColumnSampler {
+    static constexpr int E = 3 + 6 * NF;
+    static constexpr int EP = (E + 7) / 8 * 8;
+    static constexpr int CHH = CH / 2;
+    static constexpr int EPH = EP / 2;
+    static constexpr int LPC = CH / 4;              // lanes per cell: one 4-channel quad each
+    static constexpr int CPP = 64 / LPC;            // cells per pass of the wave
+    static constexpr int NZC_MAX = 12;              // longest column the host selects this path for
+    static constexpr int NPASS = (NZC_MAX + CPP - 1) / CPP;
+    float p0, p1, p2;
+    float wz0, wz1;
+    int zrel;                                       // (z cell of the sample) - zc_lo, in [0, nzc - 2]
+
+    // vx, vy: the row (wave-uniform); vz: the lane's voxel, already clamped to the row.  s_col: this wave's nzc x CH floats.
+    __device__ __forceinline__ void stage_a(const LfgcFwdArgs& a, int vx, int vy, int vz, const float* s_coord,
+                                            float* s_col, int lane) {
+        p0 = s_coord[vx]; p1 = s_coord[a.res0 + vy]; p2 = s_coord[a.res0 + a.res1 + vz];
+        // grid_sampler_unnormalize, align_corners=False: ((p + 1) * size - 1) / 2   (ATen GridSampler.h)
+        const float ix = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p0, 1.0f), (float)a.W), 1.0f), 0.5f);
+        const float iy = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p1, 1.0f), (float)a.H), 1.0f), 0.5f);
+        const float iz = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(p2, 1.0f), (float)a.D), 1.0f), 0.5f);
+        const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+        const int x0 = (int)fminf(fmaxf(fx0, -2.0f), (float)a.W);
+        const int y0 = (int)fminf(fmaxf(fy0, -2.0f), (float)a.H);
+        const int z0 = (int)fminf(fmaxf(fz0, -2.0f), (float)a.D);
+        float wx[2], wy[2];
+        wx[1] = __fsub_rn(ix, fx0); wx[0] = __fsub_rn(__fadd_rn(fx0, 1.0f), ix);
+        wy[1] = __fsub_rn(iy, fy0); wy[0] = __fsub_rn(__fadd_rn(fy0, 1.0f), iy);
+        wz1 = __fsub_rn(iz, fz0); wz0 = __fsub_rn(__fadd_rn(fz0, 1.0f), iz);
+        unsigned ox[2], oy[2];
+        const unsigned cell = 4u * (unsigned)a.Cs, row = (unsigned)a.W * cell, plane = (unsigned)a.H * row;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {          // out-of-bounds corner = zero weight on that axis; its (clamped) row is still read
+            wx[d] = ((unsigned)(x0 + d) < (unsigned)a.W) ? wx[d] : 0.0f;
+            wy[d] = ((unsigned)(y0 + d) < (unsigned)a.H) ? wy[d] : 0.0f;
+            ox[d] = (unsigned)min(max(x0 + d, 0), a.W - 1) * cell;
+            oy[d] = (unsigned)min(max(y0 + d, 0), a.H - 1) * row;
+        }
+        wz0 = ((unsigned)z0 < (unsigned)a.D) ? wz0 : 0.0f;
+        wz1 = ((unsigned)(z0 + 1) < (unsigned)a.D) ? wz1 : 0.0f;
+        const int zc_lo = __builtin_amdgcn_readfirstlane(z0);          // lane 0 holds the row's smallest z
+        zrel = min(max(z0 - zc_lo, 0), a.nzc - 2);
+        const float wxy[4] = {__fmul_rn(wx[0], wy[0]), __fmul_rn(wx[1], wy[0]), __fmul_rn(wx[0], wy[1]), __fmul_rn(wx[1], wy[1])};
+        const unsigned oxy[4] = {oy[0] + ox[0], oy[0] + ox[1], oy[1] + ox[0], oy[1] + ox[1]};
+        const int q = lane % LPC, kl = lane / LPC;
+        const float inv_nzc = 1.0f / (float)a.nzc;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            int k = ps * CPP + kl;                                     // < NPASS * CPP + 64 / LPC <= 64: exact in fp32
+            k -= a.nzc * (int)(((float)k + 0.5f) * inv_nzc);           // k mod nzc
+            const int zc = min(max(zc_lo + k, 0), a.D - 1);
+            const unsigned off = (unsigned)zc * plane + (unsigned)(q * 16);
+            f32x4 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.grid) + (off + oxy[c]));
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc.x = __builtin_fmaf(v[c].x, wxy[c], acc.x); acc.y = __builtin_fmaf(v[c].y, wxy[c], acc.y);
+                acc.z = __builtin_fmaf(v[c].z, wxy[c], acc.z); acc.w = __builtin_fmaf(v[c].w, wxy[c], acc.w);
+            }
+            *reinterpret_cast<f32x4*>(s_col + k * CH + 4 * q) = acc;
+        }
+    }
+
+    __device__ __forceinline__ void stage_b(const float* s_col, int hh, float (&B0)[CHH + EPH]) {
+        lfgc_embed_inputs<NF>(p0, p1, p2, hh, B0 + CHH);
+        const float* c0 = s_col + zrel * CH + hh * CHH;
+#pragma unroll
+        for (int c4 = 0; c4 < CHH / 4; ++c4) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(c0 + 4 * c4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(c0 + CH + 4 * c4);
+            B0[4 * c4 + 0] = __builtin_fmaf(hi.x, wz1, __fmul_rn(lo.x, wz0));
+            B0[4 * c4 + 1] = __builtin_fmaf(hi.y, wz1, __fmul_rn(lo.y, wz0));
+            B0[4 * c4 + 2] = __builtin_fmaf(hi.z, wz1, __fmul_rn(lo.z, wz0));
+            B0[4 * c4 + 3] = __builtin_fmaf(hi.w, wz1, __fmul_rn(lo.w, wz0));
+        }
     }
 };
 

@@ -235,7 +235,7 @@ __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, c
             } else {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, bh, acc, 0, 0, 0);
             }
-            if constexpr (NP > 0) {          // this gap's share of the weight stream, in the MFMA's shadow
+            if constexpr (NP > 0 && !(LFGC_ABLATE & 64)) {   // this gap's share of the weight stream, in the MFMA's shadow (diagnostics: 64 = none)
                 constexpr int gg = DG0 + g;
                 constexpr int pi_lo = gg < DSPAN ? (gg * NP + DSPAN - 1) / DSPAN : NP;
                 constexpr int pi_hi = gg + 1 < DSPAN ? ((gg + 1) * NP + DSPAN - 1) / DSPAN : NP;
@@ -279,10 +279,9 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
                                                  float* __restrict__ stash, int j, int hh, int lane, const LfgcDmaPlan& dma) {
     constexpr int MPK = SPLIT ? 3 : 1;
     constexpr int G = KS16 * MPK;
-    // the next block's pieces go out over the first 3/4 of the layer's gaps: the last one then has a quarter of the layer
-    // to land before the wave waits for it at the next barrier
+    // the next block's pieces go out over the first half of the layer's gaps (1/4 ... 1 measured alike, profiles/r3/ab_dma_policy_span.log)
 #ifndef LFGC_DMA_SPAN4
-#define LFGC_DMA_SPAN4 3
+#define LFGC_DMA_SPAN4 2
 #endif
     constexpr int DSPAN = (MT * G * LFGC_DMA_SPAN4 + 3) / 4;
     const float* s_row = s_blk + j * S + 8 * hh;              // lane half hh: bytes [32 hh, 32 hh + 32) of each 64-B k-step
@@ -352,7 +351,8 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
 #define LFGC_STAMP(k) do { } while (0)
 #endif
 
-template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT>
+// ZRUN (lattice mode only, never with STASH): z-run tiles and the column sampler (LfgcColumnSampler, lfgc_forward.h).
+template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT, bool ZRUN>
 __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwdArgs a) {
     constexpr int E = 3 + 6 * NF;
     constexpr int EP = (E + 7) / 8 * 8;
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     float* s_bias = s_scale + 16;        // b/pi of every hidden layer: LFGC_MAX_LAYERS x HP
     float* s_w = s_bias + LFGC_MAX_LAYERS * HP;   // resident: every layer block; streamed: ring of 2 x BLKMAX
     float* s_coord = s_w + (STREAM ? 2 * BLKMAX : (BLK0 + (a.L - 1) * BLK1));
+    float* s_col = s_coord + ((a.res0 + a.res1 + a.res2 + 3) & ~3) + (threadIdx.x >> 6) * (a.nzc * CH);   // ZRUN: this wave's column
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -435,15 +436,43 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
 #endif
 
     const long long N = a.n;
+    // ZRUN: tile t = (row t / tiles_per_row of the slab, z run t % tiles_per_row); the walk over a workgroup's tiles is kept
+    // in wave-uniform (x, y, run) form, advanced by the grid stride with carries -- no division per batch
+    int zr_x = 0, zr_y = 0, zr_t = 0, zr_dx = 0, zr_dy = 0, zr_dt = 0;
+    if (ZRUN) {
+        const unsigned tpr = (unsigned)a.tiles_per_row, r1 = (unsigned)a.res1;
+        const unsigned t0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WAVES + wave));
+        const unsigned row0 = t0 / tpr, stride = gridDim.x * WAVES, drow = stride / tpr;
+        zr_t = (int)(t0 - row0 * tpr); zr_x = (int)(row0 / r1); zr_y = (int)(row0 - (row0 / r1) * r1);
+        zr_dt = (int)(stride - drow * tpr); zr_dx = (int)(drow / r1); zr_dy = (int)(drow - (drow / r1) * r1);
+    }
     for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
         const long long tile_idx = batch * WAVES + wave;
-        const long long n = tile_idx * LFGC_TILE_SAMPLES + j;
-        const bool valid = n < N;
+        long long n = tile_idx * LFGC_TILE_SAMPLES + j;
+        bool valid = n < N;
         const long long nc = valid ? n : (N - 1);
         LFGC_STAMP(0);            // loop overhead / previous tail
 
         LfgcSampler<CH, NF> sampler;
-        sampler.issue(a, nc, N, s_coord, hh);           // 8 corner rows requested; used after the layer-0 barrier
+        LfgcColumnSampler<CH, NF> csampler;
+#if !(LFGC_ABLATE & 128)           // diagnostics: 128 = no input phase at all (inputs = a cheap function of the lane)
+        if constexpr (ZRUN) {
+            const bool tile_ok = tile_idx < a.ntiles;             // (a tile past the end repeats the slab's first row, unstored)
+            const int vx = tile_ok ? zr_x : 0, vy = tile_ok ? zr_y : 0, vz = (tile_ok ? zr_t : 0) * LFGC_TILE_SAMPLES + j;
+            valid = tile_ok && vz < a.res2;
+            n = ((long long)vx * a.res1 + vy) * a.res2 + vz;
+            csampler.stage_a(a, a.x_begin + vx, vy, min(vz, a.res2 - 1), s_coord, s_col, lane);
+            zr_t += zr_dt;
+            const int c1 = zr_t >= a.tiles_per_row ? 1 : 0;
+            zr_t -= c1 * a.tiles_per_row;
+            zr_y += zr_dy + c1;
+            const int c2 = zr_y >= a.res1 ? 1 : 0;
+            zr_y -= c2 * a.res1;
+            zr_x += zr_dx + c2;
+        } else {
+            sampler.issue(a, nc, N, s_coord, hh);       // 8 corner rows requested; used after the layer-0 barrier
+        }
+#endif
 
         LfgcDmaPlan dma = {hblk, s_w, BLK0 / 4, wave_s, (unsigned)lane * 16u};
         // opaque per batch: otherwise the address arithmetic of every piece of every block is hoisted out of this loop
@@ -458,7 +487,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             // my pieces of this layer's block have landed (they are older than the sampler's loads, which stay in
             // flight across the layer-0 barrier: vmcnt counts in issue order)
 #ifndef LFGC_LATE_BARRIER0
-            if (l == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (CH / 8)) : "memory");
+            if (l == 0 && !ZRUN) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (CH / 8)) : "memory");
             else
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -490,7 +519,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             float X[8 * KS16_0];
             {
                 float B0[KS0];
-                sampler.finish(hh, B0);
+#if !(LFGC_ABLATE & 128)
+                if constexpr (ZRUN) csampler.stage_b(s_col, hh, B0);
+                else sampler.finish(hh, B0);
+#else
+#pragma unroll
+                for (int s = 0; s < KS0; ++s) B0[s] = 0.01f * (float)(lane + s);
+#endif
 #pragma unroll
                 for (int s = 0; s < KS0; ++s) X[s] = B0[s];
 #pragma unroll
@@ -571,9 +606,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
 #endif
 }
 
-template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT>
+template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH, bool SPLIT, bool ZRUN>
 static int lfgc_launch_fwd16_cfg(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
-    auto kern = lfgc_fwd16_kernel<CH, MT, NF, WAVES, STREAM, STASH, SPLIT>;
+    auto kern = lfgc_fwd16_kernel<CH, MT, NF, WAVES, STREAM, STASH, SPLIT, ZRUN>;
     // the >64 KB dynamic-LDS attribute is per device: raised once per (instantiation, device); one-time, so launches
     // stay graph-capturable
     static int lds_limit_set[LFGC_MAX_DEVICES] = {0};
@@ -591,8 +626,13 @@ static int lfgc_launch_fwd16_cfg(const LfgcFwdArgs& a, int lds_bytes, int grid, 
 
 template <int CH, int MT, int NF, int WAVES, bool STREAM, bool STASH>
 static int lfgc_launch_fwd16_one(const LfgcFwdArgs& a, int lds_bytes, int grid, hipStream_t stream) {
-    return a.single ? lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, STASH, false>(a, lds_bytes, grid, stream)
-                    : lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, STASH, true>(a, lds_bytes, grid, stream);
+    if constexpr (!STASH) {
+        if (a.zrun)
+            return a.single ? lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, false, false, true>(a, lds_bytes, grid, stream)
+                            : lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, false, true, true>(a, lds_bytes, grid, stream);
+    }
+    return a.single ? lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, STASH, false, false>(a, lds_bytes, grid, stream)
+                    : lfgc_launch_fwd16_cfg<CH, MT, NF, WAVES, STREAM, STASH, true, false>(a, lds_bytes, grid, stream);
 }
 
 template <int CH, int MT, int NF>

@@ -130,8 +130,9 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
     others return None; each rank's slab crosses the fabric once (what a writer of the volume needs).
     ``gather='all'``: an all-gather -- every rank returns the full volume (world-1 times the bytes of 'root').
 
-    The slab is cut into ``chunks`` pieces (default 4) of x-rows -- whole tile planes while there are enough of them,
-    multiples of 8 rows otherwise (8 ranks on 256^3 own one tile plane each) --; each piece's collective is issued
+    The slab is cut into ``chunks`` pieces of x-rows (default: up to 4 whole tile planes, never less than a plane per
+    piece; an explicit ``chunks`` cuts on multiples of 8 rows when there are fewer planes than pieces); each piece's
+    collective is issued
     asynchronously right after the piece's kernel launch, so the transfer of piece c runs under the compute of piece
     c+1.  Pieces are received straight into views of the output volume (x is the slowest axis, so a piece of a slab is a
     contiguous range of it); only a piece that is shorter than the common piece length (ragged volumes, e.g. 255^3 =
@@ -178,9 +179,13 @@ def reconstruct_volume_sharded(dataset, net=None, tiled_res: int = 32, group=Non
                 torch.cuda.synchronize(device)
             timings.update(compute_ms=float(sum(a.elapsed_time(c) for a, c in ev)), gather_wait_ms=0.0, world_size=1)
         return out
-    # piece boundaries relative to the slab start, on tile planes, identical on every rank (from max_x)
-    want = 4 if chunks is None else max(1, int(chunks))
-    unit = tiled_res if (max_x + tiled_res - 1) // tiled_res >= want else 8
+    # piece boundaries relative to the slab start, on tile planes, identical on every rank (from max_x).  Default: up to 4
+    # pieces of WHOLE tile planes -- a piece below one plane (~0.7 ms of kernel on 256^3) costs more host time to issue
+    # than it hides: at 8 ranks on 256^3 (one plane per rank) 4 pieces of 8 rows took 2.05 ms of wall per step against
+    # 0.76 ms for one piece (profiles/r3/sharded_host_overhead.log).  An explicit `chunks` still cuts below a plane.
+    planes = (max_x + tiled_res - 1) // tiled_res
+    want = min(4, max(1, planes)) if chunks is None else max(1, int(chunks))
+    unit = tiled_res if planes >= want else 8
     units = (max_x + unit - 1) // unit
     n_chunks = max(1, min(units, want))
     cuts = [min(((c * units) // n_chunks) * unit, max_x) for c in range(n_chunks + 1)]
