@@ -283,6 +283,9 @@ struct LfgcColumnSampler {
     float p0, p1, p2;
     float wz0, wz1;
     int zrel;                                       // (z cell of the sample) - zc_lo, in [0, nzc - 2]
+    int q, kcell[NPASS];                            // the lane's channel quad and column cell per pass
+    float wxy_[4];
+    f32x4 v[NPASS][4];                              // corner quads in flight between stage_a and stage_b
 
     // vx, vy: the row (wave-uniform); vz: the lane's voxel, already clamped to the row.  s_col: this wave's nzc x CH floats.
     __device__ __forceinline__ void stage_a(const LfgcFwdArgs& a, int vx, int vy, int vz, const float* s_coord,
@@ -315,30 +318,38 @@ struct LfgcColumnSampler {
         zrel = min(max(z0 - zc_lo, 0), a.nzc - 2);
         const float wxy[4] = {__fmul_rn(wx[0], wy[0]), __fmul_rn(wx[1], wy[0]), __fmul_rn(wx[0], wy[1]), __fmul_rn(wx[1], wy[1])};
         const unsigned oxy[4] = {oy[0] + ox[0], oy[0] + ox[1], oy[1] + ox[0], oy[1] + ox[1]};
-        const int q = lane % LPC, kl = lane / LPC;
+        q = lane % LPC;
+        const int kl = lane / LPC;
         const float inv_nzc = 1.0f / (float)a.nzc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wxy_[c] = wxy[c];
+        // every pass's corner quads are requested here and contracted in stage_b: their latency runs under the embedding
+        // arithmetic and the layer-0 barrier instead of being waited out pass by pass
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             int k = ps * CPP + kl;                                     // < NPASS * CPP + 64 / LPC <= 64: exact in fp32
             k -= a.nzc * (int)(((float)k + 0.5f) * inv_nzc);           // k mod nzc
+            kcell[ps] = k;
             const int zc = min(max(zc_lo + k, 0), a.D - 1);
             const unsigned off = (unsigned)zc * plane + (unsigned)(q * 16);
-            f32x4 v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                v[c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.grid) + (off + oxy[c]));
-            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc.x = __builtin_fmaf(v[c].x, wxy[c], acc.x); acc.y = __builtin_fmaf(v[c].y, wxy[c], acc.y);
-                acc.z = __builtin_fmaf(v[c].z, wxy[c], acc.z); acc.w = __builtin_fmaf(v[c].w, wxy[c], acc.w);
-            }
-            *reinterpret_cast<f32x4*>(s_col + k * CH + 4 * q) = acc;
+                v[ps][c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.grid) + (off + oxy[c]));
         }
     }
 
-    __device__ __forceinline__ void stage_b(const float* s_col, int hh, float (&B0)[CHH + EPH]) {
+    __device__ __forceinline__ void stage_b(float* s_col, int hh, float (&B0)[CHH + EPH]) {
         lfgc_embed_inputs<NF>(p0, p1, p2, hh, B0 + CHH);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc.x = __builtin_fmaf(v[ps][c].x, wxy_[c], acc.x); acc.y = __builtin_fmaf(v[ps][c].y, wxy_[c], acc.y);
+                acc.z = __builtin_fmaf(v[ps][c].z, wxy_[c], acc.z); acc.w = __builtin_fmaf(v[ps][c].w, wxy_[c], acc.w);
+            }
+            *reinterpret_cast<f32x4*>(s_col + kcell[ps] * CH + 4 * q) = acc;
+        }
         const float* c0 = s_col + zrel * CH + hh * CHH;
 #pragma unroll
         for (int c4 = 0; c4 < CHH / 4; ++c4) {

@@ -422,6 +422,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     }
     __syncthreads();
     unsigned step = 0;
+#ifdef LFGC_PRIO_YOUNG      // diagnostics: static priority for the second-dispatched half of the workgroup
+    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 #if (LFGC_ABLATE & 8) && defined(LFGC_ANTIPHASE)
     // diagnostics: with the barriers gone, start the second wave of every SIMD LFGC_ANTIPHASE x 8k cycles late
     if (wave >= WAVES / 2) {
@@ -487,7 +490,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             // my pieces of this layer's block have landed (they are older than the sampler's loads, which stay in
             // flight across the layer-0 barrier: vmcnt counts in issue order)
 #ifndef LFGC_LATE_BARRIER0
-            if (l == 0 && !ZRUN) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(8 * (CH / 8)) : "memory");
+            // (ZRUN: the column sampler's corner quads, 4 per pass, are the youngest loads)
+            if (l == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ZRUN ? 4 * LfgcColumnSampler<CH, NF>::NPASS : 8 * (CH / 8)) : "memory");
             else
 #endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -10,13 +10,38 @@ O=$R/gpurun_out/$1
 mkdir -p $O
 cd $R
 echo "== default bench run"; python3 bench.py > $O/bench_default_run.log 2>&1; tail -c 400 $O/bench_default_run.log; echo
+# --stats averages over EVERY launch, warm-up included (the first launches of a process run 5-25 % long); the summary beside
+# it is made from the per-dispatch trace with the first WARM launches of each kernel dropped: median, mean, min, max.  That
+# mean is what bench.py's roofline.kernel_ms (HIP events over the timed steps only) has to agree with.
+summarize() {  # <kernel_trace.csv> <out.csv> <warm-up launches to drop>
+python3 - "$1" "$2" "$3" <<'PY'
+import csv, sys, statistics as st, collections
+src, dst, warm = sys.argv[1], sys.argv[2], int(sys.argv[3])
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(src)):
+    d[r['Kernel_Name']].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+rows = []
+for k, v in d.items():
+    v.sort()
+    t = [x[1] for x in v][warm if len(v) > warm else 0:]
+    rows.append((sum(t), k, len(v), len(t), st.median(t), sum(t) / len(t), min(t), max(t)))
+with open(dst, 'w') as fh:
+    w = csv.writer(fh)
+    w.writerow(['Kernel_Name', 'Calls', 'Calls_after_warmup', 'Median_ns', 'Mean_after_warmup_ns', 'Min_ns', 'Max_ns'])
+    for r in sorted(rows, reverse=True):
+        w.writerow([r[1][:160]] + list(r[2:]))
+PY
+}
 for prec in f16x2 fp32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$prec -- python3 bench.py --precision $prec --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $O/kt_$prec.log 2>&1
   cp $(ls $O/kt_$prec/*/*kernel_stats.csv | head -1) $O/bench_headline_${prec}_kernel_stats.csv
+  summarize $(ls $O/kt_$prec/*/*kernel_trace.csv | head -1) $O/bench_headline_${prec}_kernel_summary.csv 2
+  tail -c 900 $O/kt_$prec.log | grep -o '"kernel_ms": [0-9.]*' > $O/bench_headline_${prec}_kernel_ms_of_that_run.txt
 done
 for wl in cfg2 cfg5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$wl -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/kt_$wl.log 2>&1
   cp $(ls $O/kt_$wl/*/*kernel_stats.csv | head -1) $O/bench_${wl}_f16x2_kernel_stats.csv
+  summarize $(ls $O/kt_$wl/*/*kernel_trace.csv | head -1) $O/bench_${wl}_f16x2_kernel_summary.csv 1
 done
 echo "== PMC passes (headline)"
 i=0
@@ -60,17 +85,15 @@ PY
 echo "== train step (graph replay)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ts -- python3 tools/bench_trainstep.py --graph --steps 40 --warmup 5 > $O/kt_ts.log 2>&1
 cp $(ls $O/kt_ts/*/*kernel_stats.csv | head -1) $O/trainstep_cfg3_graph_kernel_stats.csv
+summarize $(ls $O/kt_ts/*/*kernel_trace.csv | head -1) $O/trainstep_cfg3_graph_kernel_summary.csv 8
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ts_sm -- python3 tools/bench_trainstep.py --graph --steps 40 --warmup 5 --drop-type smallify > $O/kt_ts_sm.log 2>&1
 cp $(ls $O/kt_ts_sm/*/*kernel_stats.csv | head -1) $O/trainstep_cfg3_smallify_graph_kernel_stats.csv
 python3 tools/bench_trainstep.py --graph --steps 100 --warmup 10 > $O/trainstep_plain.log 2>&1; tail -1 $O/trainstep_plain.log | cut -c1-200
 echo "== microbenchmarks"
-./tools/microbench/mfma_shadow > $O/mfma_shadow.log 2>&1
-./tools/microbench/hwcos_snake > $O/hwcos_snake.log 2>&1
 python3 tools/microbench/idwt_sizes.py > $O/idwt_sizes.log 2>&1; tail -4 $O/idwt_sizes.log
 python3 tests/error_stats.py > $O/fwd_error_stats.log 2>&1
-./tools/microbench/mfma_lds_mix > $O/mfma_lds_mix.log 2>&1
-[ -f tools/microbench/ablate/liblfgc_stamps.so ] && python3 tools/phase_stamps.py run > $O/phase_stamps.log 2>&1
-[ -f tools/microbench/ablate/liblfgc_stamps.so ] && python3 tools/phase_stamps.py run bwd > $O/phase_stamps_bwd.log 2>&1
+LFGC_AB_DIR=$O/st python3 tools/phase_stamps.py build > $O/stamps_build.log 2>&1 && LFGC_AB_DIR=$O/st python3 tools/phase_stamps.py run > $O/phase_stamps.log 2>&1 && LFGC_AB_DIR=$O/st python3 tools/phase_stamps.py run bwd > $O/phase_stamps_bwd.log 2>&1
+rm -rf $O/st
 [ -f tools/microbench/ablate/liblfgc_ab_base.so ] && python3 tools/ab_wavelet_cl.py run > $O/idwt_cl_ablation.log 2>&1
 echo "== channel-last level kernels: counters"
 bash tools/prof_idwt_cl.sh $1 65 > $O/idwt_cl_pmc.log 2>&1
