@@ -106,7 +106,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
         const long long ntiles = rows * tpr;
         const long long tbl4 = 4LL * (((long long)a.res0 + a.res1 + a.res2 + 3) & ~3LL) - 4LL * ((long long)a.res0 + a.res1 + a.res2);
         const long long cap = a.resident ? 80 * 1024 : 160 * 1024;
-        const long long col = 4LL * 8 * nzc * p.CH;                  // sized for the 8-wave build
+        const long long col = 4LL * 8 * nzc * (p.CH + 4);            // 8 waves x nzc padded rows (LfgcColumnSampler::CS)
         if (nzc <= 12 && ntiles < (1LL << 31) && lds_bytes + tbl4 + col <= cap) {
             a.zrun = 1; a.nzc = nzc; a.tiles_per_row = tpr; a.ntiles = ntiles;
             lds_bytes += (int)(tbl4 + col);

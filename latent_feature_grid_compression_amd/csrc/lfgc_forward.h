@@ -280,6 +280,9 @@ struct LfgcColumnSampler {
     static constexpr int CPP = 64 / LPC;            // cells per pass of the wave
     static constexpr int NZC_MAX = 12;              // longest column the host selects this path for
     static constexpr int NPASS = (NZC_MAX + CPP - 1) / CPP;
+    // LDS row of one column cell: CH floats + 4 of padding -- with 128-byte rows, rows r and r + 2 start on the same bank
+    // and the read-back (16 lanes of a ds_read_b128 group spread over 4-5 neighbouring rows) conflicted 2-3 ways
+    static constexpr int CS = CH + 4;
     float p0, p1, p2;
     float wz0, wz1;
     int zrel;                                       // (z cell of the sample) - zc_lo, in [0, nzc - 2]
@@ -348,13 +351,13 @@ struct LfgcColumnSampler {
                 acc.x = __builtin_fmaf(v[ps][c].x, wxy_[c], acc.x); acc.y = __builtin_fmaf(v[ps][c].y, wxy_[c], acc.y);
                 acc.z = __builtin_fmaf(v[ps][c].z, wxy_[c], acc.z); acc.w = __builtin_fmaf(v[ps][c].w, wxy_[c], acc.w);
             }
-            *reinterpret_cast<f32x4*>(s_col + kcell[ps] * CH + 4 * q) = acc;
+            *reinterpret_cast<f32x4*>(s_col + kcell[ps] * CS + 4 * q) = acc;
         }
-        const float* c0 = s_col + zrel * CH + hh * CHH;
+        const float* c0 = s_col + zrel * CS + hh * CHH;
 #pragma unroll
         for (int c4 = 0; c4 < CHH / 4; ++c4) {
             const f32x4 lo = *reinterpret_cast<const f32x4*>(c0 + 4 * c4);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(c0 + CH + 4 * c4);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(c0 + CS + 4 * c4);
             B0[4 * c4 + 0] = __builtin_fmaf(hi.x, wz1, __fmul_rn(lo.x, wz0));
             B0[4 * c4 + 1] = __builtin_fmaf(hi.y, wz1, __fmul_rn(lo.y, wz0));
             B0[4 * c4 + 2] = __builtin_fmaf(hi.z, wz1, __fmul_rn(lo.z, wz0));

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
     float* s_bias = s_scale + 16;        // b/pi of every hidden layer: LFGC_MAX_LAYERS x HP
     float* s_w = s_bias + LFGC_MAX_LAYERS * HP;   // resident: every layer block; streamed: ring of 2 x BLKMAX
     float* s_coord = s_w + (STREAM ? 2 * BLKMAX : (BLK0 + (a.L - 1) * BLK1));
-    float* s_col = s_coord + ((a.res0 + a.res1 + a.res2 + 3) & ~3) + (threadIdx.x >> 6) * (a.nzc * CH);   // ZRUN: this wave's column
+    float* s_col = s_coord + ((a.res0 + a.res1 + a.res2 + 3) & ~3) + (threadIdx.x >> 6) * (a.nzc * (CH + 4));   // ZRUN: this wave's column (rows of LfgcColumnSampler::CS floats)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -36,7 +36,7 @@ for prec in f16x2 fp32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$prec -- python3 bench.py --precision $prec --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $O/kt_$prec.log 2>&1
   cp $(ls $O/kt_$prec/*/*kernel_stats.csv | head -1) $O/bench_headline_${prec}_kernel_stats.csv
   summarize $(ls $O/kt_$prec/*/*kernel_trace.csv | head -1) $O/bench_headline_${prec}_kernel_summary.csv 2
-  tail -c 900 $O/kt_$prec.log | grep -o '"kernel_ms": [0-9.]*' > $O/bench_headline_${prec}_kernel_ms_of_that_run.txt
+  grep -o '"kernel_ms": [0-9.]*' $O/kt_$prec.log | head -1 > $O/bench_headline_${prec}_kernel_ms_of_that_run.txt
 done
 for wl in cfg2 cfg5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$wl -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/kt_$wl.log 2>&1
@@ -94,9 +94,8 @@ python3 tools/microbench/idwt_sizes.py > $O/idwt_sizes.log 2>&1; tail -4 $O/idwt
 python3 tests/error_stats.py > $O/fwd_error_stats.log 2>&1
 LFGC_AB_DIR=$O/st python3 tools/phase_stamps.py build > $O/stamps_build.log 2>&1 && LFGC_AB_DIR=$O/st python3 tools/phase_stamps.py run > $O/phase_stamps.log 2>&1 && LFGC_AB_DIR=$O/st python3 tools/phase_stamps.py run bwd > $O/phase_stamps_bwd.log 2>&1
 rm -rf $O/st
-[ -f tools/microbench/ablate/liblfgc_ab_base.so ] && python3 tools/ab_wavelet_cl.py run > $O/idwt_cl_ablation.log 2>&1
-echo "== channel-last level kernels: counters"
-bash tools/prof_idwt_cl.sh $1 65 > $O/idwt_cl_pmc.log 2>&1
-rm -rf $O/clpmc_*/ $O/clpmc_*.log
+echo "== sharded driver: host overhead on an 8-rank share (RCCL, world size 1)"
+python3 tools/sharded_host_overhead.py 2>&1 | grep -v "^\[W\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl\|amdgpu.ids" > $O/sharded_host_overhead.log; cat $O/sharded_host_overhead.log
+# (the channel-last wavelet level kernels are unchanged since round 2: their counters / ablations stay in profiles/r2)
 rm -rf $O/kt_*/ $O/pmc_*/
 ls $O

@@ -54,7 +54,8 @@ def main():
                                             always_gather=True, timings=tm)
 
     print('slab of one of 8 ranks on 256^3: 32 x-rows = %d samples; RCCL world size %d' % (32 * 256 * 256, dist.get_world_size()))
-    for chunks in (4, 2, 1):
+    step(1)                                  # first collective of the process: communicator set-up
+    for chunks in (4, 2, 1, None):          # None = the driver's default (pieces of whole tile planes: 1 here)
         for _ in range(5):
             step(chunks)
         torch.cuda.synchronize()
@@ -73,8 +74,8 @@ def main():
             comp.append(tm['compute_ms'])
         comp = sum(comp) / len(comp)
         # decode + pack (repeated every step like bench.py does) is inside the first slab_fn call, hence inside compute_ms
-        print('chunks=%d: wall %.3f ms/step, fused launches + decode/pack (device) %.3f ms, host-visible remainder %.3f ms = %.0f %% of wall'
-              % (chunks, wall, comp, wall - comp, 100 * (wall - comp) / wall), flush=True)
+        print('chunks=%s: wall %.3f ms/step, fused launches + decode/pack (device, events) %.3f ms, host-visible remainder %.3f ms = %.0f %% of wall'
+              % ('default' if chunks is None else chunks, wall, comp, wall - comp, 100 * (wall - comp) / wall), flush=True)
     dist.destroy_process_group()
 
 
