@@ -83,11 +83,15 @@ __device__ __forceinline__ void lfgc_snake_bwd(const float* __restrict__ slot, c
 // t computes, one barrier per step); the scatter staging aliases the ring slot that has just been consumed.
 // acc += Wt_tile . dA for one 32-row tile with f16-split operands (three MFMAs per 16-wide k-step); `arow` = LDS
 // address of (row 32m + lane&31, lane half's 32 bytes of k-step 0).
-template <int KS16, bool SPLIT>
+// `dma`: the next image's weight stream (lfgc_dma_piece, lfgc_common.h); pieces [pi0, pi0 + KS16) capped at NPW go out one
+// per k-step, in the shadow of its MFMAs, instead of all at once after the layer's barrier (NPW = 0: not streamed here).
+template <int KS16, bool SPLIT, int NPW = 0, int WAVES = 4>
 __device__ __forceinline__ f32x16 lfgc_mfma_tile16(const float* __restrict__ arow, const h16x8 (&Fhi)[KS16],
-                                                   const h16x8 (&Flo)[KS16], f32x16 acc) {
+                                                   const h16x8 (&Flo)[KS16], f32x16 acc,
+                                                   const LfgcDmaPlan* dma = nullptr, int pi0 = 0) {
 #pragma unroll
     for (int ks = 0; ks < KS16; ++ks) {
+        if constexpr (NPW > 0) { if (pi0 + ks < NPW) lfgc_dma_piece<WAVES>(*dma, pi0 + ks); }
         const h16x8 whi = *reinterpret_cast<const h16x8*>(arow + 16 * ks);
         if (SPLIT) {
             const h16x8 wlo = *reinterpret_cast<const h16x8*>(arow + 16 * ks + 4);
@@ -190,8 +194,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
     const unsigned long long bst_t0 = bst_last;
 #endif
 
+#ifndef LFGC_BWD_DMA_BURST
+#define LFGC_BWD_DMA_BURST 0         // diagnostics: 1 = every wave issues its pieces back to back after the barrier (round 2)
+#endif
+    constexpr int NPW = (H16 && !LFGC_BWD_DMA_BURST) ? ((TBMAX / 4 + 63) / 64 + WAVES - 1) / WAVES : 0;   // pieces per wave and image
+    LfgcDmaPlan dma = {a.packed, s_ring, TB1 / 4, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
     const long long N = a.n;
     for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
+        asm volatile("" : "+s"(dma.wave));                // (keeps the pieces' address arithmetic inside the loop)
         // the image of layer l was put in flight one step ago; after the barrier every wave is also done with the
         // other slot, so the next image (layer l-1, or the next batch's first) goes into it
         auto acquire = [&](int l) -> const float* {
@@ -201,8 +211,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
             LFGC_BSTAMP(2);                                   // wait for stores / DMA + barrier
             const float* img = s_ring + (step & 1) * SLOT;
             const int ln = (l == 0) ? L - 1 : l - 1;
-            if (l != 0 || batch + gridDim.x < a.nbatches)
+            if (H16 && !LFGC_BWD_DMA_BURST) {
+                // streamed piece by piece under this step's MFMAs (always a real block: after the last batch the slot is
+                // filled once more for nobody, which keeps the MFMA loops free of branches)
+                dma.src = image_src(ln);
+                dma.dst = s_ring + ((step + 1) & 1) * SLOT;
+                dma.nvec = (ln == 0 ? TB0 : TB1) / 4;
+            } else if (l != 0 || batch + gridDim.x < a.nbatches) {
                 lfgc_dma_to_lds(image_src(ln), s_ring + ((step + 1) & 1) * SLOT, ln == 0 ? TB0 : TB1, wave, lane, WAVES);
+            }
             ++step;
             return img;
         };
@@ -244,9 +261,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    acc = lfgc_mfma_tile16<2 * MT, SPLIT>(s_row + 32 * m * ST, Fhi, Flo, acc);
+                    acc = lfgc_mfma_tile16<2 * MT, SPLIT, NPW, WAVES>(s_row + 32 * m * ST, Fhi, Flo, acc, &dma, m * 2 * MT);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dH[16 * m + r] = acc[r] * is;
+                }
+                if constexpr (NPW > MT * 2 * MT) {      // narrow nets: fewer k-steps than pieces (layer 0's image is the larger one)
+                    for (int pi = MT * 2 * MT; pi < NPW; ++pi) lfgc_dma_piece<WAVES>(dma, pi);
                 }
             } else {
                 const float* s_row = acquire(l) + j * ST + 4 * hh;
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
                     f32x16 acc;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                    if (H16) acc = lfgc_mfma_tile16<2 * MT, SPLIT>(s_row + 32 * m * ST, Fhi, Flo, acc);
+                    if (H16) acc = lfgc_mfma_tile16<2 * MT, SPLIT, NPW, WAVES>(s_row + 32 * m * ST, Fhi, Flo, acc, &dma, m * 2 * MT);
                     else acc = lfgc_mfma_tile<KS1>(s_row + 32 * m * ST, dA, acc);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dX[16 * m + r] = acc[r] * is;
@@ -292,6 +312,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dX[16 * m + r] = 0.0f;
                 }
+            }
+            if constexpr (NPW > 0) {          // pieces the (few, partly skipped) layer-0 tiles had no k-step for
+                const int done = ((TXF < TXA && !a.d_pos) ? TXF : TXA) * 2 * MT;
+                for (int pi = done; pi < NPW; ++pi) lfgc_dma_piece<WAVES>(dma, pi);
             }
         }
 
@@ -426,6 +450,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
         }
         LFGC_BSTAMP(5);                                       // d_pos
     }
+    // the stream's last image (fetched for nobody) must have landed before the workgroup gives its LDS back
+    if (NPW > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef LFGC_STAMPS
     if (a.stamps && lane == 0) {
         unsigned long long* dst = a.stamps + ((long long)blockIdx.x * WAVES + wave) * 20;

@@ -4,7 +4,7 @@
 """
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OUT = os.path.join(ROOT, 'tools', 'microbench', 'ablate')
+OUT = os.environ.get('LFGC_AB_DIR') or os.path.join(ROOT, 'tools', 'microbench', 'ablate')
 names = sorted(f[len('liblfgc_ab_'):-3] for f in os.listdir(OUT) if f.startswith('liblfgc_ab_') and f.endswith('.so'))
 res = {n: [] for n in names}
 for _ in range(3):
