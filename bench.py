@@ -59,6 +59,27 @@ def traffic_bytes(workload, precision):
             return hbm[precision].get('hbm_bytes_per_launch')
     return None
 
+def profiled_counters(workload, precision):
+    """Counter-derived figures of the dominant kernel from the committed PMC passes (None without a profile of this
+    (workload, build)): matrix-pipe occupancy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), and the
+    instruction mix per 32-sample tile."""
+    if workload != 'headline':
+        return None
+    for rnd in ('r3', 'r2'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd, 'bench_headline_pmc.json')) as fh:
+                c = json.load(fh).get('sq_counters', {}).get(precision, {})
+        except (OSError, ValueError):
+            continue
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in c and 'GRBM_GUI_ACTIVE' in c:
+            tiles = 16777216 / 32
+            return {'source': 'profiles/%s/bench_headline_pmc.json' % rnd,
+                    'mfma_pipe_busy_frac_of_simd_cycles': c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024),
+                    'per_tile': {k: c[n] / tiles for k, n in (('valu', 'SQ_INSTS_VALU'), ('mfma', 'SQ_INSTS_MFMA'),
+                                                             ('lds', 'SQ_INSTS_LDS'), ('salu', 'SQ_INSTS_SALU')) if n in c}}
+    return None
+
+
 WORKLOADS = {
     # name: (volume edge, grid channels C, grid edge G, hidden H, layers L)
     'headline': dict(vol=256, C=32, G=64, H=128, L=4,
@@ -510,6 +531,7 @@ def main():
                                            'note': ('three f16 MFMAs per fp32 product block (hi/lo split)' if split else
                                                     'one MFMA per product block')},
                          'decode_pack_ms': prep_ms,
+                         'profiled': profiled_counters(args.workload, model.precision),
                          'hbm_algorithmic': {'bytes_per_sample': bytes_per_sample, 'achieved_GBs': hbm_alg_gbs,
                                              'peak_GBs': HBM_PEAK_GBS, 'frac': hbm_alg_gbs / HBM_PEAK_GBS}},
         }
