@@ -98,7 +98,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
     a.nbatches = (n + 255) / 256 * (8 / a.waves);
     // Lattice mode on the f16 builds: z-run tiles + column sampler (lfgc_forward.h) when the column a 32-voxel run touches
     // is short (volume at least ~3x finer than the grid along z: every BASELINE full-volume shape) and fits the LDS left.
-    a.zrun = 0; a.nzc = 2; a.tiles_per_row = 1; a.ntiles = 0;
+    a.zrun = 0; a.nzc = 2; a.tiles_per_row = 1; a.ntiles = 0; a.x2 = 0;
     if (h16 && !a.pos && a.coord_table && !stash && !getenv("LFGC_NO_ZRUN")) {
         const int nzc = (int)(31.0 * (double)D / (double)(a.res2 - 1) + 1e-3) + 3;
         const long long rows = (long long)(positions->x_end - positions->x_begin) * a.res1;
@@ -113,6 +113,10 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
             a.waves = (!a.resident && (ntiles + 7) / 8 >= num_cus()) ? 8 : 4;
             if (const char* e = getenv("LFGC_FWD_WAVES")) { if (!a.resident && (e[0] == '4' || e[0] == '8')) a.waves = e[0] - '0'; }
             a.nbatches = (ntiles + a.waves - 1) / a.waves;
+            // experimental (LFGC_FWD_X2=1): two tiles per wave, one wave per SIMD (lfgc_forward16x2.h; 32 channels x 128 wide)
+            if (!a.resident && p.CH == 32 && p.MT == 4 && (ntiles + 7) / 8 >= num_cus() && getenv("LFGC_FWD_X2")) {
+                a.x2 = 1; a.waves = 4; a.nbatches = (ntiles + 7) / 8;
+            }
         }
     }
     long long grid = (a.resident ? 2LL : 1LL) * num_cus();
@@ -140,7 +144,7 @@ extern "C" int lfgc_forward_f32(const lfgc_mlp_desc* desc, const lfgc_positions*
         // Range fallback: the same pass on the exact-fp32 build, enqueued behind the fast one; its workgroups return
         // at once unless the fast kernel has set *status (a sample left the f16 range: diverged or very wide model).
         // No host synchronisation, graph-capturable; costs one empty launch when nothing overflowed.
-        a.status = nullptr; a.redo_if = status; a.single = 0; a.zrun = 0;
+        a.status = nullptr; a.redo_if = status; a.single = 0; a.zrun = 0; a.x2 = 0;
         const int all32 = p.off_final, max32 = p.blk0 > p.blk1 ? p.blk0 : p.blk1, fixed32 = p.HP + 4;
         a.resident = ((fixed32 + all32) * 4 <= 80 * 1024) ? 1 : 0;
         lds_bytes = (fixed32 + (a.resident ? all32 : 2 * max32)) * 4;

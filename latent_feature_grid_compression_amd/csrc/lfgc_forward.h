@@ -51,6 +51,7 @@ struct LfgcFwdArgs {
     // row of the slab; tiles_per_row = ceil(res2 / 32), ntiles = rows * tiles_per_row, nzc = z cells a tile's column holds
     int zrun, nzc, tiles_per_row;
     long long ntiles;
+    int x2;                    // z-run launches: the two-tiles-per-wave kernel (lfgc_forward16x2.h); nbatches counts passes of 8 tiles
 };
 
 // Lattice coordinate of voxel v along one axis, formed like field_from_net does per tile
