@@ -27,10 +27,11 @@
 // them; about five independent VALU instructions issue in its shadow (tools/microbench/mfma_shadow.hip: 32.0 -> 33.5
 // cycles per MFMA with 0 -> 5 fillers, +4.5 cycles for every further one; with two waves per SIMD the limit is the
 // same per MFMA).  Each layer therefore runs as one stream of "gaps" = one MFMA + one slice of other work, written
-// out gap by gap with a scheduling fence after each: the A-operand reads of the NEXT k-step (2 ds_read_b128), and one
-// third of the activation + hi/lo split of one accumulator PAIR of the PREVIOUS output tile (3-4 VALU).  The
-// activation of a layer's last tile rides under the first MFMAs of the next layer (whose last two k-steps are the
-// ones that need it).
+// out gap by gap with a scheduling fence after each: an A-operand read for a later k-step (ds_read_b128), now and then
+// a 1-KiB piece of the next layer's weight stream (lfgc_dma_piece), and 3-4 VALU instructions of the activation + hi/lo
+// split of the PREVIOUS output tile -- dependency levels of different accumulator pairs, so that the instructions of
+// one gap do not wait for each other (LfgcEpilogue, lfgc_epilogue_gap).  The activation of a layer's last tile rides
+// under the first MFMAs of the next layer (whose last two k-steps are the ones that need it).
 #pragma once
 #include <utility>
 #include "lfgc_forward.h"
