@@ -198,7 +198,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_bwd_data_kernel(const Lfgc
 #define LFGC_BWD_DMA_BURST 0         // diagnostics: 1 = every wave issues its pieces back to back after the barrier (round 2)
 #endif
     constexpr int NPW = (H16 && !LFGC_BWD_DMA_BURST) ? ((TBMAX / 4 + 63) / 64 + WAVES - 1) / WAVES : 0;   // pieces per wave and image
-    LfgcDmaPlan dma = {a.packed, s_ring, TB1 / 4, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u};
+    LfgcDmaPlan dma = {a.packed, s_ring, TB1 / 4, __builtin_amdgcn_readfirstlane(wave), (unsigned)lane * 16u, 0ull, 0u};
     const long long N = a.n;
     for (long long batch = blockIdx.x; batch < a.nbatches; batch += gridDim.x) {
         asm volatile("" : "+s"(dma.wave));                // (keeps the pieces' address arithmetic inside the loop)

@@ -206,7 +206,7 @@ struct LfgcOperands {
 // `w` holds the operands of this tile's first LFGC_PF k-steps on entry and of the next tile's on exit.
 // Weight streaming: the NP pieces this wave owes of the NEXT block (lfgc_dma_piece; NP = 0: resident build) are
 // requested one at a time in gaps DG0 + g < DSPAN of the layer, evenly spread.
-template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, int NP, int DG0, int DSPAN, int WAVES, class EPI>
+template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, int NP, int NVEC, int DG0, int DSPAN, int WAVES, class EPI>
 __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, const float* __restrict__ arow_next,
                                                u32x4 (&INhi)[KS16], u32x4 (&INlo)[KS16], f32x16& acc,
                                                LfgcOperands& w, EPI& ep, const f32x16& eacc,
@@ -240,7 +240,7 @@ __device__ __forceinline__ void lfgc_tile_gaps(const float* __restrict__ arow, c
                 constexpr int gg = DG0 + g;
                 constexpr int pi_lo = gg < DSPAN ? (gg * NP + DSPAN - 1) / DSPAN : NP;
                 constexpr int pi_hi = gg + 1 < DSPAN ? ((gg + 1) * NP + DSPAN - 1) / DSPAN : NP;
-                lfgc_static_for<(gg < DSPAN ? pi_hi - pi_lo : 0)>([&](auto p_c) { lfgc_dma_piece<WAVES>(dma, pi_lo + decltype(p_c)::value); });
+                lfgc_static_for<(gg < DSPAN ? pi_hi - pi_lo : 0)>([&](auto p_c) { lfgc_dma_piece_ct<WAVES, pi_lo + decltype(p_c)::value, NVEC>(dma); });
             }
             // the operands of k-step ks + LFGC_PF (running on into the next tile's rows), one read per gap
             const float* nsrc = (ks + LFGC_PF < KS16) ? arow + 16 * (ks + LFGC_PF)
@@ -272,7 +272,7 @@ struct LfgcCarry {
 // One hidden layer on a 32-sample tile.  IN = KS16 input fragments (the last two still owed by `carry` when
 // HAS_CARRY: they are produced under this layer's first MFMAs), OUT = this layer's 2*MT output fragments (all but the
 // last two; those are `out_carry`'s to produce), or with LAST the head's partial dot product in `ydot` (complete).
-template <int KS16, int MT, int S, bool STASH, bool LAST, bool SPLIT, bool HAS_CARRY, int NP, int WAVES>
+template <int KS16, int MT, int S, bool STASH, bool LAST, bool SPLIT, bool HAS_CARRY, int NP, int NVEC, int WAVES>
 __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk, u32x4 (&INhi)[KS16], u32x4 (&INlo)[KS16],
                                                  const LfgcCarry& carry, float inv_scale, const float* __restrict__ s_bias,
                                                  u32x4 (&OUThi)[2 * MT], u32x4 (&OUTlo)[2 * MT], LfgcCarry& out_carry,
@@ -311,7 +311,7 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
                 INhi[KS16 - 2] = ehi[0]; INhi[KS16 - 1] = ehi[1]; INlo[KS16 - 2] = elo[0]; INlo[KS16 - 1] = elo[1];
             }
         }
-        lfgc_tile_gaps<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0), NP, 0, DSPAN, WAVES>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo,
+        lfgc_tile_gaps<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0), NP, NVEC, 0, DSPAN, WAVES>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo,
                                                     accs[0], w, ep, carry.acc, ehi, elo, ydot, tmax, dma);
     }
     // tiles 1 .. MT-1: each shadows the tile before it
@@ -321,7 +321,7 @@ __device__ __forceinline__ void lfgc_layer_fwd16(const float* __restrict__ s_blk
         ep.inv_scale = inv_scale; ep.bias = bias_l + 32 * (m - 1); ep.wf = wf_l + 32 * (m - 1);
         ep.stash = STASH ? stash_l + (m - 1) * (16 * 64) : nullptr;
         u32x4 ehi[2], elo[2];
-        lfgc_tile_gaps<KS16, SPLIT, G, false, NP, m * G, DSPAN, WAVES>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr,
+        lfgc_tile_gaps<KS16, SPLIT, G, false, NP, NVEC, m * G, DSPAN, WAVES>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr,
                                               INhi, INlo, accs[m & 1], w, ep, accs[(m - 1) & 1], ehi, elo, ydot, tmax, dma);
         if (!LAST) {
             OUThi[2 * (m - 1)] = ehi[0]; OUThi[2 * (m - 1) + 1] = ehi[1];
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
         }
 #endif
 
-        LfgcDmaPlan dma = {hblk, s_w, BLK0 / 4, wave_s, (unsigned)lane * 16u};
+        LfgcDmaPlan dma = {hblk, s_w, BLK0 / 4, wave_s, (unsigned)lane * 16u, 0ull, 0u};
         // opaque per batch: otherwise the address arithmetic of every piece of every block is hoisted out of this loop
         // into ~60 SGPRs that do not exist (spilled to VGPR lanes, v_readlane in the gaps)
         asm volatile("" : "+s"(dma.wave));
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             dma.src = hblk + (ln == 0 ? 0 : BLK0 + (long long)(ln - 1) * BLK1);
             dma.dst = s_w + ((step + 1) & 1) * BLKMAX;
             dma.nvec = (ln == 0 ? BLK0 : BLK1) / 4;
+            lfgc_dma_plan_block(dma);
             ++step;
             return blk;
         };
@@ -554,10 +555,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             const float* blk = acquire(0);
 #endif
             if (L == 1)
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT, false, NP0, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, true, SPLIT, false, NP0, BLK0 / 4, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
                                                                             s_final, ydot, tmax, stash_of(0), j, hh, lane, dma);
             else
-                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false, SPLIT, false, NP1, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                lfgc_layer_fwd16<KS16_0, MT, S0, STASH, false, SPLIT, false, NP1, BLK1 / 4, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
                                                                              s_final, ydot, tmax, stash_of(0), j, hh, lane, dma);
         }
         // hidden layers 1 .. L-2 in ping-pong pairs, then the last one with the head folded in
@@ -565,23 +566,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void lfgc_fwd16_kernel(const LfgcFwd
             int l = 1;
             for (; l + 2 < L; l += 2) {
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, BLK1 / 4, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
                                                                             s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
                 blk = acquire(l + 1);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, WAVES>(blk, Bhi, Blo, cb, s_scale[9 + l], s_bias + (l + 1) * HP, Ahi, Alo, ca,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, BLK1 / 4, WAVES>(blk, Bhi, Blo, cb, s_scale[9 + l], s_bias + (l + 1) * HP, Ahi, Alo, ca,
                                                                             s_final, ydot, tmax, stash_of(l + 1), j, hh, lane, dma);
             }
             if (l + 1 < L) {       // one more non-final layer: A -> B, final consumes B
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, false, SPLIT, true, NP1, BLK1 / 4, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
                                                                             s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
                 ++l;
                 blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true, NP0, WAVES>(blk, Bhi, Blo, cb, s_scale[8 + l], s_bias + l * HP, Ahi, Alo, ca,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true, NP0, BLK0 / 4, WAVES>(blk, Bhi, Blo, cb, s_scale[8 + l], s_bias + l * HP, Ahi, Alo, ca,
                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
             } else if (l < L) {    // final layer consumes A
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true, NP0, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                lfgc_layer_fwd16<KS16_1, MT, S1, STASH, true, SPLIT, true, NP0, BLK0 / 4, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
                                                                            s_final, ydot, tmax, stash_of(l), j, hh, lane, dma);
             }
         }

@@ -13,7 +13,7 @@
 // The gaps of one output tile for both sample tiles T = 0, 1 (see lfgc_tile_gaps): per (k-step, product) two MFMAs
 // sharing the A operand, then that gap's slice of the weight stream, the next operand read, and the slices of the two
 // pending epilogues.
-template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, int NP, int DG0, int DSPAN, int WAVES, class EPI>
+template <int KS16, bool SPLIT, int GA, bool E_IS_IN_TAIL, int NP, int NVEC, int DG0, int DSPAN, int WAVES, class EPI>
 __device__ __forceinline__ void lfgc_tile_gaps2(const float* __restrict__ arow, const float* __restrict__ arow_next,
                                                 u32x4 (&INhi)[2][KS16], u32x4 (&INlo)[2][KS16], f32x16 (&acc)[2],
                                                 LfgcOperands& w, EPI (&ep)[2], const f32x16 (&eacc)[2],
@@ -59,7 +59,7 @@ __device__ __forceinline__ void lfgc_tile_gaps2(const float* __restrict__ arow, 
                         constexpr int gg = DG0 + g;
                         constexpr int pi_lo = gg < DSPAN ? (gg * NP + DSPAN - 1) / DSPAN : NP;
                         constexpr int pi_hi = gg + 1 < DSPAN ? ((gg + 1) * NP + DSPAN - 1) / DSPAN : NP;
-                        lfgc_static_for<(gg < DSPAN ? pi_hi - pi_lo : 0)>([&](auto p_c) { lfgc_dma_piece<WAVES>(dma, pi_lo + decltype(p_c)::value); });
+                        lfgc_static_for<(gg < DSPAN ? pi_hi - pi_lo : 0)>([&](auto p_c) { lfgc_dma_piece_ct<WAVES, pi_lo + decltype(p_c)::value, NVEC>(dma); });
                     }
                     const float* nsrc = (ks + LFGC_PF < KS16) ? arow + 16 * (ks + LFGC_PF)
                                                               : (arow_next ? arow_next + 16 * (ks + LFGC_PF - KS16) : nullptr);
@@ -79,7 +79,7 @@ __device__ __forceinline__ void lfgc_tile_gaps2(const float* __restrict__ arow, 
 }
 
 // One layer on the wave's two tiles (see lfgc_layer_fwd16; never with a stash).
-template <int KS16, int MT, int S, bool LAST, bool SPLIT, bool HAS_CARRY, int NP, int WAVES>
+template <int KS16, int MT, int S, bool LAST, bool SPLIT, bool HAS_CARRY, int NP, int NVEC, int WAVES>
 __device__ __forceinline__ void lfgc_layer_fwd16x2(const float* __restrict__ s_blk, u32x4 (&INhi)[2][KS16], u32x4 (&INlo)[2][KS16],
                                                    const LfgcCarry (&carry)[2], float inv_scale, const float* __restrict__ s_bias,
                                                    u32x4 (&OUThi)[2][2 * MT], u32x4 (&OUTlo)[2][2 * MT], LfgcCarry (&out_carry)[2],
@@ -117,7 +117,7 @@ __device__ __forceinline__ void lfgc_layer_fwd16x2(const float* __restrict__ s_b
                 }
             }
         }
-        lfgc_tile_gaps2<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0), NP, 0, DSPAN, WAVES>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo,
+        lfgc_tile_gaps2<KS16, SPLIT, GA0, (HAS_CARRY && GA0 > 0), NP, NVEC, 0, DSPAN, WAVES>(s_row, MT > 1 ? s_row + 32 * S : nullptr, INhi, INlo,
                                                     accs[0], w, ep, cacc, ehi, elo, ydot, tmax, dma);
     }
     lfgc_static_for<MT - 1>([&](auto m_c) {
@@ -128,7 +128,7 @@ __device__ __forceinline__ void lfgc_layer_fwd16x2(const float* __restrict__ s_b
             ep[t].inv_scale = inv_scale; ep[t].bias = bias_l + 32 * (m - 1); ep[t].wf = wf_l + 32 * (m - 1); ep[t].stash = nullptr;
         }
         u32x4 ehi[2][2], elo[2][2];
-        lfgc_tile_gaps2<KS16, SPLIT, G, false, NP, m * G, DSPAN, WAVES>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr,
+        lfgc_tile_gaps2<KS16, SPLIT, G, false, NP, NVEC, m * G, DSPAN, WAVES>(s_row + 32 * m * S, m + 1 < MT ? s_row + 32 * (m + 1) * S : nullptr,
                                               INhi, INlo, accs[m & 1], w, ep, accs[(m - 1) & 1], ehi, elo, ydot, tmax, dma);
         if (!LAST) {
 #pragma unroll
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void lfgc_fwd16x2_kernel(const LfgcFwdArgs 
             zx[t] += dzx + c2;
         }
 
-        LfgcDmaPlan dma = {hblk, s_w, BLK0 / 4, wave_s, (unsigned)lane * 16u};
+        LfgcDmaPlan dma = {hblk, s_w, BLK0 / 4, wave_s, (unsigned)lane * 16u, 0ull, 0u};
         asm volatile("" : "+s"(dma.wave));
         auto acquire = [&](int l) -> const float* {
             LFGC_STAMP(2 + 2 * (l < 6 ? l : 6));
@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, 1) void lfgc_fwd16x2_kernel(const LfgcFwdArgs 
             dma.src = hblk + (ln == 0 ? 0 : BLK0 + (long long)(ln - 1) * BLK1);
             dma.dst = s_w + ((step + 1) & 1) * BLKMAX;
             dma.nvec = (ln == 0 ? BLK0 : BLK1) / 4;
+            lfgc_dma_plan_block(dma);
             ++step;
             return blk;
         };
@@ -305,33 +306,33 @@ __global__ __launch_bounds__(256, 1) void lfgc_fwd16x2_kernel(const LfgcFwdArgs 
                 }
             }
             if (L == 1)
-                lfgc_layer_fwd16x2<KS16_0, MT, S0, true, SPLIT, false, NP0, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                lfgc_layer_fwd16x2<KS16_0, MT, S0, true, SPLIT, false, NP0, BLK0 / 4, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
                                                                                  s_final, ydot, tmax, j, hh, dma);
             else
-                lfgc_layer_fwd16x2<KS16_0, MT, S0, false, SPLIT, false, NP1, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
+                lfgc_layer_fwd16x2<KS16_0, MT, S0, false, SPLIT, false, NP1, BLK1 / 4, WAVES>(blk, X0hi, X0lo, ca, s_scale[8], s_bias, Ahi, Alo, ca,
                                                                                   s_final, ydot, tmax, j, hh, dma);
         }
         {
             int l = 1;
             for (; l + 2 < L; l += 2) {
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16x2<KS16_1, MT, S1, false, SPLIT, true, NP1, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                lfgc_layer_fwd16x2<KS16_1, MT, S1, false, SPLIT, true, NP1, BLK1 / 4, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
                                                                                  s_final, ydot, tmax, j, hh, dma);
                 blk = acquire(l + 1);
-                lfgc_layer_fwd16x2<KS16_1, MT, S1, false, SPLIT, true, NP1, WAVES>(blk, Bhi, Blo, cb, s_scale[9 + l], s_bias + (l + 1) * HP, Ahi, Alo, ca,
+                lfgc_layer_fwd16x2<KS16_1, MT, S1, false, SPLIT, true, NP1, BLK1 / 4, WAVES>(blk, Bhi, Blo, cb, s_scale[9 + l], s_bias + (l + 1) * HP, Ahi, Alo, ca,
                                                                                  s_final, ydot, tmax, j, hh, dma);
             }
             if (l + 1 < L) {
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16x2<KS16_1, MT, S1, false, SPLIT, true, NP1, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                lfgc_layer_fwd16x2<KS16_1, MT, S1, false, SPLIT, true, NP1, BLK1 / 4, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
                                                                                  s_final, ydot, tmax, j, hh, dma);
                 ++l;
                 blk = acquire(l);
-                lfgc_layer_fwd16x2<KS16_1, MT, S1, true, SPLIT, true, NP0, WAVES>(blk, Bhi, Blo, cb, s_scale[8 + l], s_bias + l * HP, Ahi, Alo, ca,
+                lfgc_layer_fwd16x2<KS16_1, MT, S1, true, SPLIT, true, NP0, BLK0 / 4, WAVES>(blk, Bhi, Blo, cb, s_scale[8 + l], s_bias + l * HP, Ahi, Alo, ca,
                                                                                 s_final, ydot, tmax, j, hh, dma);
             } else if (l < L) {
                 const float* blk = acquire(l);
-                lfgc_layer_fwd16x2<KS16_1, MT, S1, true, SPLIT, true, NP0, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
+                lfgc_layer_fwd16x2<KS16_1, MT, S1, true, SPLIT, true, NP0, BLK0 / 4, WAVES>(blk, Ahi, Alo, ca, s_scale[8 + l], s_bias + l * HP, Bhi, Blo, cb,
                                                                                 s_final, ydot, tmax, j, hh, dma);
             }
         }
