@@ -386,14 +386,19 @@ def test_forward_matches_oracle_on_synthetic_models(dev, C, G, H, L, n, tol, pre
           % (precision, C, G, H, L, e_hip, e_cpu, rel_err(y, yref)))
 
 
-def test_cfg5_grid_three_level_code_and_large_lattice(dev):
-    """BASELINE cfg 5 shape: 128^3 x 32-channel grid coded with 3 wavelet levels (encode_volume(num_levels=3)),
-    MLP 4x128.  Random positions vs the oracle, and a slab of the 1024^3 lattice (x = 512..543, generated in-kernel)
-    vs the same voxels pushed through the explicit-position path."""
+@pytest.mark.parametrize('num_levels', [3, None])
+def test_cfg5_grid_three_level_code_and_large_lattice(dev, num_levels):
+    """BASELINE cfg 5 shape: 128^3 x 32-channel grid, MLP 4x128, coded with 3 wavelet levels as BASELINE names it
+    (encode_volume(num_levels=3)) and with the reference's own default depth (model/Feature_Grid_Model.py:85:
+    pywt.dwt_max_level(128, 4) = 5 levels).  Random positions vs the oracle, and a slab of the 1024^3 lattice
+    (x = 512..543, generated in-kernel) vs the same voxels pushed through the explicit-position path."""
     from latent_feature_grid_compression_amd.data.IndexDataset import IndexDataset
     from latent_feature_grid_compression_amd.visualization import OutputToVTK as V
-    m, sm = build_synth(32, 128, 128, 4, seed=4242, dev=dev, num_levels=3)
-    assert np.asarray(m.shape_array).tolist() == [[34, 34, 34], [65, 65, 65], [128, 128, 128]]
+    m, sm = build_synth(32, 128, 128, 4, seed=4242, dev=dev, num_levels=num_levels)
+    if num_levels == 3:
+        assert np.asarray(m.shape_array).tolist() == [[34, 34, 34], [65, 65, 65], [128, 128, 128]]
+    else:
+        assert len(m.feature_grid) == 6 and np.asarray(m.shape_array)[-1].tolist() == [128, 128, 128]
     rng = np.random.default_rng(5)
     pos = torch.from_numpy(rng.uniform(-1, 1, (20000, 3)).astype(np.float32))
     m.train()
